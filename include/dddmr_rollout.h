@@ -1,0 +1,266 @@
+/*
+ * dddmr_rollout.h -- C ABI of the MI355X local-planner rollout engine.
+ *
+ * One call (dddmr_rollout_tick) replaces the inner section of the reference's
+ * Local_Planner::computeVelocityCommand
+ *   (src/dddmr_local_planner/local_planner/src/local_planner.cpp:535-587):
+ *   re-initialise theories -> generate all trajectories -> update critic shared
+ *   data (kd-tree build) -> score every trajectory -> pick the best one.
+ *
+ * All paths cited below are relative to /root/reference/src/dddmr_local_planner/
+ * unless they start with dddmr_perception_3d/ or dddmr_sys_core/.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; the caller owns every buffer it passes
+ *     in and it only has to stay valid for the duration of the call;
+ *   - every function returns 0 (DDDMR_OK) or a negative dddmr_status;
+ *   - no exceptions cross this boundary, no callbacks into the caller;
+ *   - a context is externally serialised exactly like the reference serialises
+ *     ticks (perception mutex local_planner.cpp:498, critics mutex :577); the
+ *     library additionally takes an internal mutex per call.  set_cloud /
+ *     set_scan may be called from the sensor-callback thread while another
+ *     thread ticks (the device cloud is double-buffered).
+ *   - the library never runs any of this on the CPU: with no usable HIP device
+ *     dddmr_rollout_create fails with DDDMR_ERR_NO_DEVICE.
+ */
+#ifndef DDDMR_ROLLOUT_H_
+#define DDDMR_ROLLOUT_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDDMR_ROLLOUT_ABI_VERSION 1
+#define DDDMR_MAX_CRITICS 8
+#define DDDMR_NAME_LEN 64
+
+/* library status codes (return values) */
+typedef enum {
+  DDDMR_OK = 0,
+  DDDMR_ERR_BAD_ARG = -1,
+  DDDMR_ERR_NO_DEVICE = -2,
+  DDDMR_ERR_HIP = -3,
+  /* stacked_generator.cpp:82-91: unknown theory name is FATAL-logged and yields
+     zero trajectories; here it is an explicit error. */
+  DDDMR_ERR_UNKNOWN_THEORY = -4,
+  DDDMR_ERR_CAPACITY = -5,
+  DDDMR_ERR_STATE = -6
+} dddmr_status;
+
+/* dddmr_sys_core/include/dddmr_sys_core/dddmr_enum_states.h:46-54 (numeric
+   values are part of the boundary).  The engine itself only produces
+   ALL_TRAJECTORIES_FAIL or TRAJECTORY_FOUND; the other codes stay in the host
+   driver (local_planner.cpp:484-524,597-607). */
+typedef enum {
+  DDDMR_TF_FAIL = 0,
+  DDDMR_PRUNE_PLAN_FAIL = 1,
+  DDDMR_ALL_TRAJECTORIES_FAIL = 2,
+  DDDMR_PERCEPTION_MALFUNCTION = 3,
+  DDDMR_TRAJECTORY_FOUND = 4,
+  DDDMR_PATH_BLOCKED_WAIT = 5,
+  DDDMR_PATH_BLOCKED_REPLANNING = 6
+} dddmr_planner_state;
+
+/* trajectory_generators.xml: the three theory plugins. */
+typedef enum {
+  DDDMR_THEORY_DD_SIMPLE = 0,        /* theories/dd_simple_trajectory_generator_theory.cpp */
+  DDDMR_THEORY_OMNI_SIMPLE = 1,      /* theories/omni_simple_trajectory_generator_theory.cpp */
+  DDDMR_THEORY_DD_ROTATE_INPLACE = 2 /* theories/dd_rotate_inplace_theory.cpp */
+} dddmr_theory_kind;
+
+/* mpc_critics.xml: the seven critic plugins. */
+typedef enum {
+  DDDMR_CRITIC_COLLISION = 0,          /* models/collision_model.cpp */
+  DDDMR_CRITIC_COLLISION_MIN_MAX = 1,  /* models/collision_min_max_model.cpp */
+  DDDMR_CRITIC_STICK_PATH = 2,         /* models/stick_path_model.cpp */
+  DDDMR_CRITIC_PURE_PURSUIT = 3,       /* models/pure_pursuit_model.cpp */
+  DDDMR_CRITIC_TOWARD_GLOBAL_PLAN = 4, /* models/toward_global_plan_model.cpp */
+  DDDMR_CRITIC_SHORTEST_ANGLE = 5,     /* models/shortest_angle_model.cpp */
+  DDDMR_CRITIC_TWIRLING = 6            /* models/twirling_model.cpp */
+} dddmr_critic_kind;
+
+/* Per-trajectory codes reported in costs[] (stacked_scoring_model.cpp:75-93:
+   the first negative critic return becomes the trajectory cost). */
+#define DDDMR_COST_COLLISION (-1.0)      /* collision_model.cpp:136-139 */
+#define DDDMR_COST_PURE_PURSUIT_GUARD (-4.0) /* pure_pursuit_model.cpp:62-64 */
+#define DDDMR_COST_NN_FAIL (-12.0)       /* toward_global_plan_model.cpp:74 */
+/* Sample whose generateTrajectory() returned false (dd_simple...cpp:364-385);
+   the reference never queues such a trajectory (local_planner.cpp:551-555). */
+#define DDDMR_COST_NOT_GENERATED (-100.0)
+
+/* One critic of a theory's stack.  `weight` is the plugin's ".weight"
+   parameter (read by every model; unused by collision / stick_path exactly as
+   in the reference), translation/orientation weights are PurePursuitModel's
+   (pure_pursuit_model.cpp:50-56). */
+typedef struct {
+  int32_t kind; /* dddmr_critic_kind */
+  int32_t reserved;
+  double weight;
+  double translation_weight;
+  double orientation_weight;
+} dddmr_critic_config;
+
+/* One named theory = limits + params of the generator plugin
+   (dd_simple...cpp:47-134, omni_simple...cpp:47-158, dd_rotate_inplace...cpp:47-129)
+   + robot cuboid + the ordered critic stack bound to it through
+   "<critic>.trajectory_generator" (mpc_critics/src/mpc_critics_ros.cpp:71-79). */
+typedef struct {
+  char name[DDDMR_NAME_LEN];
+  int32_t kind; /* dddmr_theory_kind */
+  int32_t use_motor_constraint;
+
+  /* limits */
+  double min_vel_x, max_vel_x;
+  double min_vel_y, max_vel_y;         /* omni only */
+  double min_vel_trans, max_vel_trans; /* omni only */
+  double min_vel_theta, max_vel_theta;
+  double acc_lim_x, acc_lim_y, acc_lim_theta;
+  double deceleration_ratio;
+  double max_motor_shaft_rpm, wheel_diameter, gear_ratio, robot_radius;
+
+  /* params */
+  double controller_frequency;
+  double sim_time;
+  double linear_x_sample, linear_y_sample, angular_z_sample;
+  double sim_granularity, angular_sim_granularity;
+  double rotation_speed; /* rotate-in-place only (dd_rotate_inplace_theory.cpp:127) */
+
+  /* 8 cuboid vertices in base_link, in the reference push order
+     blb, brb, blt, flb, brt, frt, flt, frb (dd_simple...cpp:211-218); the
+     collision critic derives the box axes from [0]->[3], [0]->[1], [0]->[2]. */
+  float cuboid[8][3];
+
+  /* Bench-mode extensions; 0 = reference behaviour.
+     bench_fixed_steps > 0: every trajectory uses exactly that many steps and
+       dt = sim_time / steps (the reference's commented-out fixed variant,
+       dd_simple...cpp:391-394).
+     bench_no_zero_insert != 0: VelocityIterator does not insert the extra 0.0
+       sample (velocity_iterator.h:63-65) so sample counts are exact powers. */
+  int32_t bench_fixed_steps;
+  int32_t bench_no_zero_insert;
+
+  int32_t n_critics;
+  int32_t reserved;
+  dddmr_critic_config critics[DDDMR_MAX_CRITICS];
+} dddmr_theory_config;
+
+typedef struct {
+  uint32_t abi_version; /* DDDMR_ROLLOUT_ABI_VERSION */
+  int32_t device;       /* HIP device ordinal */
+  /* Trajectory shard of this context: the context scores the
+     contiguous global sample range [rank*N/world, (rank+1)*N/world).
+     world_size <= 1 means the whole batch. */
+  int32_t rank;
+  int32_t world_size;
+  uint32_t max_points;       /* capacity of the aggregate observation cloud */
+  uint32_t max_trajectories; /* capacity of one tick's sample list (global N) */
+  uint32_t max_steps;        /* capacity of one trajectory's horizon */
+  uint32_t max_plan_poses;   /* capacity of the prune plan */
+  int32_t n_theories;
+  int32_t reserved;
+  const dddmr_theory_config* theories;
+} dddmr_rollout_config;
+
+/* Inputs of one control tick; mirrors what computeVelocityCommand copies into
+   the generator and critic shared data (local_planner.cpp:528-533, 580-583). */
+typedef struct {
+  double robot_pose[7];  /* trans_gbl2b_: x y z qx qy qz qw */
+  double robot_twist[3]; /* robot_state_.twist.twist: linear.x linear.y angular.z */
+  /* perception shared data current_allowed_max_linear_speed_ (<= 0: none,
+     dd_simple...cpp:260-262, omni_simple...cpp:406-411) */
+  double allowed_max_linear_speed;
+  /* ModelSharedData::heading_deviation_ (local_planner.cpp:262-263,295-296) */
+  double heading_deviation;
+} dddmr_tick_input;
+
+typedef struct {
+  int32_t planner_state;     /* DDDMR_ALL_TRAJECTORIES_FAIL or DDDMR_TRAJECTORY_FOUND */
+  int32_t best_index;        /* global sample index of the winner, -1 if none */
+  double best_cost;          /* -1.0 if none (local_planner.cpp:450) */
+  double vx, vy, wz;         /* best_traj.{xv_,yv_,thetav_}; 0 if none (trajectory.cpp:34-37) */
+  uint32_t n_samples;        /* global number of velocity samples this tick */
+  uint32_t n_local;          /* samples scored by this context's shard */
+  uint32_t local_begin;      /* first global sample index of the shard */
+  uint32_t n_points_binned;  /* cloud points inside the local costmap tile */
+  /* packed argmin key of this shard, see dddmr_rollout_pack_key */
+  int64_t key;
+  float device_ms;           /* HIP-event time of the tick's kernels */
+  float reserved;
+} dddmr_rollout_result;
+
+/* Optional per-trajectory outputs of the last tick (caller-allocated). */
+typedef struct {
+  double* costs;      /* [n_local] accumulated cost or reject code */
+  int32_t* steps;     /* [n_local] generated steps (0 = not generated) */
+  float* samples;     /* [n_local][3] vx vy wz of each sample */
+} dddmr_rollout_debug;
+
+typedef struct dddmr_rollout_ctx dddmr_rollout_ctx;
+
+/* Replaces Trajectory_Generators_ROS / MPC_Critics_ROS plugin loading
+   (trajectory_generators/src/trajectory_generators_ros.cpp:45-84,
+    mpc_critics/src/mpc_critics_ros.cpp:45-83). */
+int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** out);
+void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx);
+
+/* Aggregate observation in the global frame = output of
+   StackedPerception::aggregateObservations
+   (dddmr_perception_3d/src/stacked_perception.cpp:128-140).  xyzi points at
+   n_points records, stride_bytes apart, each starting with float x,y,z
+   (PCL PointXYZI: stride 32; packed xyzi: 16; packed xyz: 12). */
+int dddmr_rollout_set_cloud(dddmr_rollout_ctx* ctx, const float* xyzi,
+                            size_t n_points, size_t stride_bytes);
+
+/* Fused local-mode perception feed = MultiLayerSpinningLidar::cbSensor
+   (dddmr_perception_3d/plugins/multilayer_spinning_lidar.cpp:177-281):
+   sensor->base transform, PassThrough crop |x|,|y| <= window, 0 <= z <= height,
+   0.1 m VoxelGrid centroid downsample, base->global transform; the result
+   becomes the aggregate observation without leaving the device.
+   T_* are x y z qx qy qz qw. */
+int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_points,
+                           size_t stride_bytes, const double T_base_sensor[7],
+                           const double T_gbl_base[7], double perception_window_size,
+                           double marking_height, uint32_t* n_out_points);
+
+/* Copy the current aggregate observation back (debug / parity of set_scan). */
+int dddmr_rollout_get_cloud(dddmr_rollout_ctx* ctx, float* xyzi_out, size_t capacity,
+                            size_t* n_points);
+
+/* Prune plan = output of Local_Planner::prunePlan (local_planner.cpp:374-445);
+   poses are x y z qx qy qz qw in the global frame. */
+int dddmr_rollout_set_prune_plan(dddmr_rollout_ctx* ctx, const double* poses_xyz_qxyzw,
+                                 size_t n_poses);
+
+/* One control tick for the named theory. */
+int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name,
+                       const dddmr_tick_input* in, dddmr_rollout_result* out);
+
+/* Multi-rank hosts: after every rank's tick, min-reduce result.key over the
+   ranks (one 8-byte all-reduce) and resolve the winner on every rank. */
+int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key,
+                          dddmr_rollout_result* inout);
+
+/* Per-trajectory outputs of the last tick (any pointer may be NULL). */
+int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg);
+
+/* Best trajectory poses of the last tick for visualisation
+   (local_planner.cpp:472-478): poses_out[n][7] x y z qx qy qz qw. */
+int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out,
+                                 size_t capacity, size_t* n_poses);
+
+/* Argmin key: min over keys == minimum cost, ties -> highest index (the
+   reference's `<=` scan keeps the LAST minimal trajectory,
+   local_planner.cpp:460-463).  cost < 0 (rejected) -> INT64_MAX. */
+int64_t dddmr_rollout_pack_key(double cost, uint32_t global_index);
+int32_t dddmr_rollout_key_index(int64_t key); /* -1 for the "none" key */
+
+const char* dddmr_rollout_last_error(dddmr_rollout_ctx* ctx);
+const char* dddmr_rollout_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDDMR_ROLLOUT_H_ */

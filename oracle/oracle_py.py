@@ -1,0 +1,138 @@
+"""ctypes binding of oracle/liboracle.so (TEST INFRASTRUCTURE ONLY)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass
+
+import numpy as np
+
+from dddmr_navigation_amd import _capi as K
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+
+
+class OracleResult(C.Structure):
+    _fields_ = [
+        ("planner_state", C.c_int32),
+        ("best_index", C.c_int32),
+        ("best_cost", C.c_double),
+        ("vx", C.c_double), ("vy", C.c_double), ("wz", C.c_double),
+        ("n_samples", C.c_uint32),
+        ("n_local", C.c_uint32),
+        ("n_generated", C.c_uint32),
+        ("reserved", C.c_uint32),
+        ("k_sum", C.c_uint64),
+        ("steps_eval", C.c_uint64),
+        ("steps_total", C.c_uint64),
+        ("t_generate_s", C.c_double), ("t_kdtree_s", C.c_double), ("t_score_s", C.c_double),
+    ]
+
+
+def load(build_if_missing: bool = True) -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(_HERE, "liboracle.so")
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} missing; run `make -C oracle`")
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    lib = C.CDLL(path)
+    lib.oracle_velocity_iterator.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_void_p, C.c_int]
+    lib.oracle_velocity_iterator.restype = C.c_int
+    lib.oracle_samples.argtypes = [C.POINTER(K.TheoryConfig), C.POINTER(K.TickInput), C.c_void_p, C.c_int]
+    lib.oracle_samples.restype = C.c_int
+    lib.oracle_generate.argtypes = [C.POINTER(K.TheoryConfig), C.POINTER(K.TickInput), C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    lib.oracle_generate.restype = C.c_int
+    lib.oracle_radius_count.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
+                                        C.c_float, C.c_void_p]
+    lib.oracle_radius_count.restype = C.c_int
+    lib.oracle_tick.argtypes = [C.POINTER(K.TheoryConfig), C.c_void_p, C.c_size_t, C.c_size_t,
+                                C.c_void_p, C.c_size_t, C.POINTER(K.TickInput), C.c_uint32, C.c_uint32,
+                                C.c_int, C.POINTER(OracleResult), C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_void_p]
+    lib.oracle_tick.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def velocity_iterator(mn: float, mx: float, n: int, no_zero_insert: bool = False) -> np.ndarray:
+    lib = load()
+    out = np.zeros(4096, dtype=np.float64)
+    k = lib.oracle_velocity_iterator(mn, mx, n, int(no_zero_insert), _ptr(out), out.size)
+    return out[:k].copy()
+
+
+def samples(theory: K.TheoryConfig, tick_in: K.TickInput) -> np.ndarray:
+    lib = load()
+    n = lib.oracle_samples(C.byref(theory), C.byref(tick_in), None, 0)
+    out = np.zeros((max(n, 1), 3), dtype=np.float32)
+    lib.oracle_samples(C.byref(theory), C.byref(tick_in), _ptr(out), n)
+    return out[:n]
+
+
+def generate(theory: K.TheoryConfig, tick_in: K.TickInput, sample, capacity: int = 4096):
+    """-> (poses[S,7] f64, cuboids[S,8,3] f32, minmax[S,2,3] f32); S == 0 if rejected."""
+    lib = load()
+    s = np.asarray(sample, dtype=np.float32).reshape(3)
+    poses = np.zeros((capacity, 7), dtype=np.float64)
+    cub = np.zeros((capacity, 8, 3), dtype=np.float32)
+    mm = np.zeros((capacity, 2, 3), dtype=np.float32)
+    n = lib.oracle_generate(C.byref(theory), C.byref(tick_in), _ptr(s), _ptr(poses), _ptr(cub), _ptr(mm), capacity)
+    assert n <= capacity
+    return poses[:n], cub[:n], mm[:n]
+
+
+def radius_count(cloud_xyz: np.ndarray, queries: np.ndarray, radius: float) -> np.ndarray:
+    lib = load()
+    cloud = np.ascontiguousarray(cloud_xyz, dtype=np.float32)
+    q = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, 3)
+    counts = np.zeros(len(q), dtype=np.int32)
+    lib.oracle_radius_count(_ptr(cloud), cloud.shape[0], cloud.strides[0], _ptr(q), len(q), radius, _ptr(counts))
+    return counts
+
+
+@dataclass
+class TickOut:
+    result: OracleResult
+    costs: np.ndarray
+    steps: np.ndarray
+    samples: np.ndarray
+    last_poses: np.ndarray
+    min_margin: np.ndarray | None
+
+
+def tick(theory: K.TheoryConfig, cloud: np.ndarray, plan: np.ndarray, tick_in: K.TickInput,
+         begin: int = 0, end: int = 0xFFFFFFFF, n_threads: int = 1, want_margin: bool = False) -> TickOut:
+    """One oracle control tick.  cloud: [P, >=3] float32 (row stride = record
+    stride), plan: [M,7] float64."""
+    lib = load()
+    cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+    if cloud.ndim != 2 or (cloud.shape[0] and cloud.shape[1] < 3):
+        raise ValueError("cloud must be [P, >=3]")
+    plan = np.ascontiguousarray(plan, dtype=np.float64).reshape(-1, 7)
+    n = lib.oracle_samples(C.byref(theory), C.byref(tick_in), None, 0)
+    b = min(begin, n)
+    e = max(b, min(end, n))
+    nl = e - b
+    costs = np.zeros(max(nl, 1), dtype=np.float64)
+    steps = np.zeros(max(nl, 1), dtype=np.int32)
+    smp = np.zeros((max(nl, 1), 3), dtype=np.float32)
+    lastp = np.zeros((max(nl, 1), 7), dtype=np.float64)
+    mm = np.zeros(max(nl, 1), dtype=np.float32) if want_margin else None
+    res = OracleResult()
+    stride = cloud.strides[0] if cloud.shape[0] else 16
+    rc = lib.oracle_tick(C.byref(theory), _ptr(cloud), cloud.shape[0], stride, _ptr(plan), plan.shape[0],
+                         C.byref(tick_in), begin, end, n_threads, C.byref(res), _ptr(costs), _ptr(steps),
+                         _ptr(smp), _ptr(lastp), _ptr(mm))
+    if rc != 0:
+        raise RuntimeError(f"oracle_tick failed: {rc}")
+    return TickOut(res, costs[:nl], steps[:nl], smp[:nl], lastp[:nl], None if mm is None else mm[:nl])
