@@ -1,0 +1,796 @@
+// rollout_engine.hip -- context, host-side theory initialisation and the C-ABI
+// (include/dddmr_rollout.h) of the MI355X local-planner rollout engine.
+//
+// Host responsibilities (cheap, per tick): the dynamic-window sample axes of the
+// theory's initialise() (dd_simple_trajectory_generator_theory.cpp:236-295,
+// omni_simple_...cpp:260-332, dd_rotate_inplace_theory.cpp:229-274), the local
+// costmap tile's extent, and launching the five kernels of rollout_kernels.hip.h.
+// Everything proportional to N_traj x N_steps or to the cloud runs on the GPU.
+//
+// Citations are relative to /root/reference/src/dddmr_local_planner/.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rollout_kernels.hip.h"
+#include "perception_kernels.hip.h"
+
+using namespace dddmr;
+
+namespace {
+
+constexpr uint32_t kCapCells = 1u << 20;
+constexpr int kMaxAxis = 4096;
+
+struct Window {              // result of a theory's initialise()
+  std::vector<float> ax, ay, ath;
+  bool list_mode = false;
+  std::vector<float4> list;  // explicit samples (rotate-in-place, motor-constraint filter)
+  size_t count() const { return list_mode ? list.size() : ax.size() * ay.size() * ath.size(); }
+};
+
+// velocity_iterator.h:44-69 -- even samples in [lo,hi], max(2,n) of them, an
+// extra 0.0 where the range straddles zero, last sample forced to hi.
+void velocity_samples(double lo, double hi, int n, bool insert_zero, std::vector<float>& out) {
+  out.clear();
+  if (lo == hi) {
+    out.push_back((float)lo);
+    return;
+  }
+  n = std::max(2, n);
+  const double step = (hi - lo) / double(std::max(1, n - 1));
+  double next = lo;
+  for (int j = 0; j < n - 1; ++j) {
+    const double cur = next;
+    next += step;
+    out.push_back((float)cur);
+    if (insert_zero && cur < 0 && next > 0) out.push_back(0.0f);
+  }
+  out.push_back((float)hi);
+}
+
+bool motor_rpm_ok(const dddmr_theory_config& c, float v, float w) {
+  // dd_simple...cpp:297-312, dd_rotate_inplace_theory.cpp:276-286
+  const double vr = v + c.robot_radius * w;
+  const double vl = v - c.robot_radius * w;
+  const double rpm_r = vr * c.gear_ratio * 60. / 3.1415926 / c.wheel_diameter;
+  const double rpm_l = vl * c.gear_ratio * 60. / 3.1415926 / c.wheel_diameter;
+  return !(std::fabs(rpm_r) >= c.max_motor_shaft_rpm || std::fabs(rpm_l) >= c.max_motor_shaft_rpm);
+}
+
+// The dynamic window is computed in float (Eigen::Vector3f max_vel/min_vel) from
+// double limits, exactly like the theories' initialise().
+void make_window(const dddmr_theory_config& c, const dddmr_tick_input& in, Window& w) {
+  w = Window();
+  if (!(c.linear_x_sample * c.angular_z_sample > 0)) {
+    w.list_mode = true;  // no samples at all
+    return;
+  }
+  const bool zero = c.bench_no_zero_insert == 0;
+  const double period = 1.0 / c.controller_frequency;
+  const double vx = in.robot_twist[0], vy = in.robot_twist[1], wz = in.robot_twist[2];
+  const float accx = (float)c.acc_lim_x, accy = (float)c.acc_lim_y, acct = (float)c.acc_lim_theta;
+  const double max_th = c.max_vel_theta, min_th = -1.0 * c.max_vel_theta;
+
+  if (c.kind == DDDMR_THEORY_DD_ROTATE_INPLACE) {
+    w.list_mode = true;
+    const float sp = (float)c.rotation_speed, sn = (float)(-1.0 * c.rotation_speed);
+    if (motor_rpm_ok(c, 0.f, sp)) w.list.push_back(make_float4(0.f, 0.f, sp, 0.f));
+    if (motor_rpm_ok(c, 0.f, sn)) w.list.push_back(make_float4(0.f, 0.f, sn, 0.f));
+    return;
+  }
+
+  float hi_x, lo_x, hi_t, lo_t;
+  hi_t = (float)std::min(max_th, wz + acct * period);
+  lo_t = (float)std::max(min_th, wz - acct * period);
+  if (c.kind == DDDMR_THEORY_DD_SIMPLE) {
+    double cap_x = c.max_vel_x;
+    if (in.allowed_max_linear_speed > 0.0) cap_x = std::min(cap_x, in.allowed_max_linear_speed);
+    hi_x = (float)std::min(cap_x, vx + accx * period);
+    lo_x = (float)std::max(c.min_vel_x, vx / c.deceleration_ratio);
+    if (hi_x < lo_x) {  // speed zone tighter than the robot can decelerate (:273-276)
+      lo_x = (float)(vx / c.deceleration_ratio);
+      hi_x = (float)(vx / c.deceleration_ratio);
+    }
+    velocity_samples(lo_x, hi_x, (int)c.linear_x_sample, zero, w.ax);
+    velocity_samples(lo_t, hi_t, (int)c.angular_z_sample, zero, w.ath);
+    w.ay.assign(1, 0.0f);
+    if (c.use_motor_constraint) {  // filtered list keeps the x-major / theta-minor order
+      w.list_mode = true;
+      for (float x : w.ax)
+        for (float t : w.ath)
+          if (motor_rpm_ok(c, x, t)) w.list.push_back(make_float4(x, 0.f, t, 0.f));
+    }
+    return;
+  }
+  // omni (omni_simple...cpp:283-312)
+  float hi_y, lo_y;
+  hi_x = (float)std::min(c.max_vel_x, vx + accx * period);
+  hi_y = (float)std::min(c.max_vel_y, vy + accy * period);
+  lo_x = (float)std::max(c.min_vel_x, vx - accx * period);
+  lo_y = (float)std::max(c.min_vel_y, vy - accy * period);
+  if (vx >= c.max_vel_x / c.deceleration_ratio) lo_x = (float)std::max(c.min_vel_x, vx / c.deceleration_ratio);
+  else if (vx <= c.min_vel_x / c.deceleration_ratio) hi_x = (float)std::min(c.max_vel_x, vx / c.deceleration_ratio);
+  if (vy >= c.max_vel_y / c.deceleration_ratio) lo_y = (float)std::max(c.min_vel_y, vy / c.deceleration_ratio);
+  else if (vy <= c.min_vel_y / c.deceleration_ratio) hi_y = (float)std::min(c.max_vel_y, vy / c.deceleration_ratio);
+  velocity_samples(lo_x, hi_x, (int)c.linear_x_sample, zero, w.ax);
+  velocity_samples(lo_y, hi_y, (int)c.linear_y_sample, zero, w.ay);
+  velocity_samples(lo_t, hi_t, (int)c.angular_z_sample, zero, w.ath);
+}
+
+void quat_to_rot(const double p[7], double R[9]) {
+  // Eigen::Quaterniond(w,x,y,z).toRotationMatrix(), as tf2::transformToEigen builds it
+  const double x = p[3], y = p[4], z = p[5], w = p[6];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1 - (tyy + tzz); R[1] = txy - twz;       R[2] = txz + twy;
+  R[3] = txy + twz;       R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
+}
+
+float absmax(const std::vector<float>& v) {
+  float m = 0.f;
+  for (float x : v) m = std::max(m, std::fabs(x));
+  return m;
+}
+
+}  // namespace
+
+struct dddmr_rollout_ctx {
+  dddmr_rollout_config cfg{};
+  std::vector<dddmr_theory_config> theories;
+  int device = 0;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, cloud_ready[2] = {nullptr, nullptr};
+
+  // device memory
+  float4* cloud_dev[2] = {nullptr, nullptr};
+  uint32_t cloud_n[2] = {0, 0};
+  uint2* pt_slot = nullptr;
+  float4* sorted = nullptr;
+  uint32_t *cell_count = nullptr, *cell_start = nullptr;
+  float* axes_dev = nullptr;
+  float4* samples_dev = nullptr;
+  float4* plan_dev = nullptr;
+  double* costs = nullptr;
+  int32_t* steps = nullptr;
+  float4* samples_out = nullptr;
+  int64_t* best_key = nullptr;
+  uint32_t* overflow = nullptr;
+  DevResult* result_dev = nullptr;
+  double* poses_dev = nullptr;
+  // perception feed scratch
+  PerceptionScratch feed{};
+
+  // pinned host memory
+  float4* cloud_stage = nullptr;
+  float* small_stage = nullptr;  // axes / sample list / plan / scan upload
+  DevResult* result_host = nullptr;
+
+  // prune plan (host copy)
+  uint32_t plan_m = 0;
+  double plan_last[7] = {0, 0, 0, 0, 0, 0, 1};
+
+  // cloud double buffer
+  std::mutex cloud_mu;
+  std::condition_variable cloud_cv;
+  int front = 0;      // buffer the next tick reads
+  int busy = -1;      // buffer a running tick is reading
+  bool front_pending = false;
+
+  std::mutex tick_mu;
+  std::string last_error;
+
+  // last tick (for get_debug / get_best_poses / resolve)
+  DevTick last{};
+  bool have_last = false;
+  Window last_window;
+  float cell_size = 0.25f;
+  int tile_override = 0;
+};
+
+namespace {
+
+int fail(dddmr_rollout_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->last_error = buf;
+  return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                   \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(ctx, DDDMR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                      \
+  } while (0)
+
+const dddmr_theory_config* find_theory(const dddmr_rollout_ctx* ctx, const char* name) {
+  for (const auto& t : ctx->theories)
+    if (std::strncmp(t.name, name, DDDMR_NAME_LEN) == 0) return &t;
+  return nullptr;
+}
+
+// Extent of the local costmap tile: every cloud point that can be inside any
+// cuboid of any trajectory of this tick.  A pose stays within rho =
+// max speed * sim_time of base_link in the body xy-plane, a cuboid vertex
+// within rv of its pose (any yaw), so the body-frame box
+// [-(rho+rv), rho+rv]^2 x [vz_min, vz_max] bounds all vertices; points further
+// than 1 m from every pose are ignored by the critic's radius search anyway
+// (collision_model.cpp:122).
+void tile_extent(const dddmr_theory_config& c, const Window& w, const double R[9], const double t[3],
+                 double sim_time, float rmin[3], float rmax[3]) {
+  double rho;
+  if (c.kind == DDDMR_THEORY_DD_ROTATE_INPLACE) {
+    rho = 0.0;
+  } else if (w.list_mode) {
+    double m = 0;
+    for (const auto& s : w.list) m = std::max(m, std::hypot((double)s.x, (double)s.y));
+    rho = m * sim_time;
+  } else {
+    rho = std::hypot((double)absmax(w.ax), (double)absmax(w.ay)) * sim_time;
+  }
+  rho = rho * 1.001 + 0.01;  // float state rounding
+  double rv = 0, vz0 = 1e30, vz1 = -1e30;
+  for (int k = 0; k < 8; ++k) {
+    rv = std::max(rv, std::hypot((double)c.cuboid[k][0], (double)c.cuboid[k][1]));
+    vz0 = std::min(vz0, (double)c.cuboid[k][2]);
+    vz1 = std::max(vz1, (double)c.cuboid[k][2]);
+  }
+  const double e = rho + rv;
+  const double margin = 0.02;
+  for (int i = 0; i < 3; ++i) {
+    double lo = 1e30, hi = -1e30;
+    for (int corner = 0; corner < 8; ++corner) {
+      const double bx = (corner & 1) ? e : -e, by = (corner & 2) ? e : -e, bz = (corner & 4) ? vz1 : vz0;
+      const double v = R[3 * i + 0] * bx + R[3 * i + 1] * by + R[3 * i + 2] * bz + t[i];
+      lo = std::min(lo, v);
+      hi = std::max(hi, v);
+    }
+    // radius criterion: within 1 m of some pose, poses within rho of base_link
+    lo = std::max(lo, t[i] - (rho + 1.0));
+    hi = std::min(hi, t[i] + (rho + 1.0));
+    rmin[i] = (float)(lo - margin);
+    rmax[i] = (float)(hi + margin);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dddmr_rollout_version(void) { return "dddmr-rollout-mi355x 0.1 (gfx950)"; }
+
+size_t dddmr_rollout_sizeof(int which) {
+  switch (which) {
+    case 0: return sizeof(dddmr_critic_config);
+    case 1: return sizeof(dddmr_theory_config);
+    case 2: return sizeof(dddmr_rollout_config);
+    case 3: return sizeof(dddmr_tick_input);
+    case 4: return sizeof(dddmr_rollout_result);
+    case 5: return sizeof(dddmr_rollout_debug);
+    default: return 0;
+  }
+}
+
+int64_t dddmr_rollout_pack_key(double cost, uint32_t global_index) { return pack_key(cost, global_index); }
+int32_t dddmr_rollout_key_index(int64_t key) { return key_index(key); }
+
+const char* dddmr_rollout_last_error(dddmr_rollout_ctx* ctx) {
+  return ctx ? ctx->last_error.c_str() : "null context";
+}
+
+void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->cloud_dev[i]) (void)hipFree(ctx->cloud_dev[i]);
+    if (ctx->cloud_ready[i]) (void)hipEventDestroy(ctx->cloud_ready[i]);
+  }
+  void* dev[] = {ctx->pt_slot, ctx->sorted, ctx->cell_count, ctx->cell_start, ctx->axes_dev,
+                 ctx->samples_dev, ctx->plan_dev, ctx->costs, ctx->steps, ctx->samples_out,
+                 ctx->best_key, ctx->overflow, ctx->result_dev, ctx->poses_dev};
+  for (void* p : dev)
+    if (p) (void)hipFree(p);
+  perception_free(ctx->feed);
+  if (ctx->cloud_stage) (void)hipHostFree(ctx->cloud_stage);
+  if (ctx->small_stage) (void)hipHostFree(ctx->small_stage);
+  if (ctx->result_host) (void)hipHostFree(ctx->result_host);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  delete ctx;
+}
+
+int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** out) {
+  if (!cfg || !out) return DDDMR_ERR_BAD_ARG;
+  *out = nullptr;
+  if (cfg->abi_version != DDDMR_ROLLOUT_ABI_VERSION) return DDDMR_ERR_BAD_ARG;
+  if (cfg->n_theories <= 0 || !cfg->theories) return DDDMR_ERR_BAD_ARG;
+  if (cfg->max_points == 0 || cfg->max_trajectories == 0 || cfg->max_steps == 0) return DDDMR_ERR_BAD_ARG;
+  if (cfg->max_trajectories >= (1u << kKeyIndexBits)) return DDDMR_ERR_CAPACITY;
+  if (cfg->max_plan_poses > (uint32_t)kMaxPlan) return DDDMR_ERR_CAPACITY;
+  for (int i = 0; i < cfg->n_theories; ++i) {
+    const auto& t = cfg->theories[i];
+    if (t.n_critics < 0 || t.n_critics > DDDMR_MAX_CRITICS) return DDDMR_ERR_BAD_ARG;
+    if (t.kind < 0 || t.kind > DDDMR_THEORY_DD_ROTATE_INPLACE) return DDDMR_ERR_BAD_ARG;
+  }
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return DDDMR_ERR_NO_DEVICE;
+  if (cfg->device < 0 || cfg->device >= n_dev) return DDDMR_ERR_NO_DEVICE;
+
+  auto* ctx = new dddmr_rollout_ctx();
+  ctx->cfg = *cfg;
+  ctx->theories.assign(cfg->theories, cfg->theories + cfg->n_theories);
+  ctx->cfg.theories = ctx->theories.data();
+  ctx->device = cfg->device;
+  if (const char* e = std::getenv("DDDMR_CELL")) {
+    const float v = (float)std::atof(e);
+    if (v > 0.01f && v < 10.f) ctx->cell_size = v;
+  }
+  if (const char* e = std::getenv("DDDMR_TILE")) ctx->tile_override = std::atoi(e);
+
+  auto init = [&]() -> int {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev0));
+    HIPCHK(ctx, hipEventCreate(&ctx->ev1));
+    const size_t P = cfg->max_points, N = cfg->max_trajectories;
+    const size_t plan_cap = std::max<uint32_t>(cfg->max_plan_poses, 1);
+    for (int i = 0; i < 2; ++i) {
+      HIPCHK(ctx, hipMalloc(&ctx->cloud_dev[i], P * sizeof(float4)));
+      HIPCHK(ctx, hipEventCreateWithFlags(&ctx->cloud_ready[i], hipEventDisableTiming));
+    }
+    HIPCHK(ctx, hipMalloc(&ctx->pt_slot, P * sizeof(uint2)));
+    HIPCHK(ctx, hipMalloc(&ctx->sorted, P * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&ctx->cell_count, (kCapCells + 1) * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->cell_start, (kCapCells + 1) * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(ctx->cell_count, 0, (kCapCells + 1) * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->axes_dev, 3 * kMaxAxis * sizeof(float)));
+    HIPCHK(ctx, hipMalloc(&ctx->samples_dev, N * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&ctx->plan_dev, plan_cap * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&ctx->costs, N * sizeof(double)));
+    HIPCHK(ctx, hipMalloc(&ctx->steps, N * sizeof(int32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->samples_out, N * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&ctx->best_key, sizeof(int64_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->overflow, sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->result_dev, sizeof(DevResult)));
+    HIPCHK(ctx, hipMalloc(&ctx->poses_dev, (size_t)cfg->max_steps * 7 * sizeof(double)));
+    HIPCHK(ctx, hipHostMalloc(&ctx->cloud_stage, P * sizeof(float4), hipHostMallocDefault));
+    const size_t small = std::max<size_t>({3 * kMaxAxis * sizeof(float), N * sizeof(float4),
+                                           plan_cap * sizeof(float4)});
+    HIPCHK(ctx, hipHostMalloc(&ctx->small_stage, small, hipHostMallocDefault));
+    HIPCHK(ctx, hipHostMalloc(&ctx->result_host, sizeof(DevResult), hipHostMallocDefault));
+    const int rc = perception_alloc(ctx->feed, P);
+    if (rc != 0) return fail(ctx, DDDMR_ERR_HIP, "perception scratch allocation failed");
+    HIPCHK(ctx, hipDeviceSynchronize());
+    return DDDMR_OK;
+  };
+  const int rc = init();
+  if (rc != DDDMR_OK) {
+    fprintf(stderr, "dddmr_rollout_create: %s\n", ctx->last_error.c_str());
+    dddmr_rollout_destroy(ctx);
+    return rc;
+  }
+  *out = ctx;
+  return DDDMR_OK;
+}
+
+// Publish a device-side cloud buffer as the new front buffer.
+static void publish_cloud(dddmr_rollout_ctx* ctx, int idx, uint32_t n) {
+  std::lock_guard<std::mutex> lk(ctx->cloud_mu);
+  ctx->cloud_n[idx] = n;
+  ctx->front = idx;
+  ctx->front_pending = true;
+}
+
+// Pick the back buffer; if a running tick still reads it, wait for that tick.
+static int acquire_back(dddmr_rollout_ctx* ctx) {
+  std::unique_lock<std::mutex> lk(ctx->cloud_mu);
+  const int back = 1 - ctx->front;
+  ctx->cloud_cv.wait(lk, [&] { return ctx->busy != back; });
+  return back;
+}
+
+int dddmr_rollout_set_cloud(dddmr_rollout_ctx* ctx, const float* xyzi, size_t n_points,
+                            size_t stride_bytes) {
+  if (!ctx) return DDDMR_ERR_BAD_ARG;
+  if (n_points > 0 && (!xyzi || stride_bytes < 12 || stride_bytes % 4 != 0))
+    return fail(ctx, DDDMR_ERR_BAD_ARG, "set_cloud: bad pointer/stride");
+  if (n_points > ctx->cfg.max_points)
+    return fail(ctx, DDDMR_ERR_CAPACITY, "set_cloud: %zu points > max_points %u", n_points, ctx->cfg.max_points);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int back = acquire_back(ctx);
+  // repack to float4 (PCL PointXYZI is 32 bytes wide) in pinned memory
+  const size_t sf = stride_bytes / 4;
+  const bool has_i = stride_bytes >= 16;
+  for (size_t i = 0; i < n_points; ++i) {
+    const float* p = xyzi + i * sf;
+    ctx->cloud_stage[i] = make_float4(p[0], p[1], p[2], has_i ? p[3] : 0.f);
+  }
+  if (n_points) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->cloud_dev[back], ctx->cloud_stage, n_points * sizeof(float4),
+                               hipMemcpyHostToDevice, ctx->copy_stream));
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->cloud_ready[back], ctx->copy_stream));
+  // the pinned staging buffer is reused by the next call
+  HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+  publish_cloud(ctx, back, (uint32_t)n_points);
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_points,
+                           size_t stride_bytes, const double T_base_sensor[7],
+                           const double T_gbl_base[7], double perception_window_size,
+                           double marking_height, uint32_t* n_out_points) {
+  if (!ctx || !T_base_sensor || !T_gbl_base) return DDDMR_ERR_BAD_ARG;
+  if (n_points > 0 && (!xyz || stride_bytes < 12 || stride_bytes % 4 != 0))
+    return fail(ctx, DDDMR_ERR_BAD_ARG, "set_scan: bad pointer/stride");
+  if (n_points > ctx->cfg.max_points)
+    return fail(ctx, DDDMR_ERR_CAPACITY, "set_scan: %zu points > max_points %u", n_points, ctx->cfg.max_points);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int back = acquire_back(ctx);
+  const size_t sf = stride_bytes / 4;
+  for (size_t i = 0; i < n_points; ++i) {
+    const float* p = xyz + i * sf;
+    ctx->cloud_stage[i] = make_float4(p[0], p[1], p[2], 0.f);
+  }
+  FeedParams fp;
+  quat_to_rot(T_base_sensor, fp.Rbs);
+  quat_to_rot(T_gbl_base, fp.Rgb);
+  for (int i = 0; i < 3; ++i) {
+    fp.tbs[i] = T_base_sensor[i];
+    fp.tgb[i] = T_gbl_base[i];
+  }
+  fp.n = (int)n_points;
+  fp.window = (float)perception_window_size;
+  fp.height = (float)marking_height;
+  uint32_t n_out = 0;
+  const int rc = perception_feed(ctx->feed, fp, ctx->cloud_stage, ctx->cloud_dev[back], ctx->copy_stream, &n_out);
+  if (rc != 0) return fail(ctx, DDDMR_ERR_HIP, "set_scan: perception feed failed (%d)", rc);
+  HIPCHK(ctx, hipEventRecord(ctx->cloud_ready[back], ctx->copy_stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
+  publish_cloud(ctx, back, n_out);
+  if (n_out_points) *n_out_points = n_out;
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_get_cloud(dddmr_rollout_ctx* ctx, float* xyzi_out, size_t capacity, size_t* n_points) {
+  if (!ctx || !n_points) return DDDMR_ERR_BAD_ARG;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  int idx;
+  uint32_t n;
+  {
+    std::lock_guard<std::mutex> lk(ctx->cloud_mu);
+    idx = ctx->front;
+    n = ctx->cloud_n[idx];
+  }
+  *n_points = n;
+  if (!xyzi_out) return DDDMR_OK;
+  if (capacity < n) return fail(ctx, DDDMR_ERR_CAPACITY, "get_cloud: capacity %zu < %u", capacity, n);
+  if (n) HIPCHK(ctx, hipMemcpy(xyzi_out, ctx->cloud_dev[idx], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_set_prune_plan(dddmr_rollout_ctx* ctx, const double* poses, size_t n_poses) {
+  if (!ctx) return DDDMR_ERR_BAD_ARG;
+  if (n_poses > 0 && !poses) return fail(ctx, DDDMR_ERR_BAD_ARG, "set_prune_plan: null poses");
+  if (n_poses > ctx->cfg.max_plan_poses)
+    return fail(ctx, DDDMR_ERR_CAPACITY, "set_prune_plan: %zu poses > max_plan_poses %u", n_poses,
+                ctx->cfg.max_plan_poses);
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  // ModelSharedData::updateData: positions as float PointXYZI (model_shared_data.h:83-91)
+  std::vector<float4> xyz(std::max<size_t>(n_poses, 1));
+  for (size_t i = 0; i < n_poses; ++i)
+    xyz[i] = make_float4((float)poses[7 * i + 0], (float)poses[7 * i + 1], (float)poses[7 * i + 2], 0.f);
+  if (n_poses) {
+    HIPCHK(ctx, hipMemcpy(ctx->plan_dev, xyz.data(), n_poses * sizeof(float4), hipMemcpyHostToDevice));
+    std::memcpy(ctx->plan_last, poses + 7 * (n_poses - 1), 7 * sizeof(double));
+  }
+  ctx->plan_m = (uint32_t)n_poses;
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_tick_input* in,
+                       dddmr_rollout_result* out) {
+  if (!ctx || !theory_name || !in || !out) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  std::memset(out, 0, sizeof(*out));
+  out->planner_state = DDDMR_ALL_TRAJECTORIES_FAIL;
+  out->best_index = -1;
+  out->best_cost = -1.0;
+  out->key = kKeyNone;
+  const dddmr_theory_config* th = find_theory(ctx, theory_name);
+  if (!th) return fail(ctx, DDDMR_ERR_UNKNOWN_THEORY, "unknown theory '%s'", theory_name);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+
+  // ---- initialise(): velocity samples of this tick ----
+  Window& w = ctx->last_window;
+  make_window(*th, *in, w);
+  const size_t N = w.count();
+  if (N > ctx->cfg.max_trajectories)
+    return fail(ctx, DDDMR_ERR_CAPACITY, "%zu samples > max_trajectories %u", N, ctx->cfg.max_trajectories);
+  if (!w.list_mode && (w.ax.size() > (size_t)kMaxAxis || w.ay.size() > (size_t)kMaxAxis || w.ath.size() > (size_t)kMaxAxis))
+    return fail(ctx, DDDMR_ERR_CAPACITY, "sample axis longer than %d", kMaxAxis);
+  const int world = std::max(1, ctx->cfg.world_size);
+  const int rank = std::min(std::max(0, ctx->cfg.rank), world - 1);
+  const uint32_t begin = (uint32_t)((uint64_t)rank * N / world);
+  const uint32_t end = (uint32_t)((uint64_t)(rank + 1) * N / world);
+  out->n_samples = (uint32_t)N;
+  out->local_begin = begin;
+  out->n_local = end - begin;
+
+  DevTick k{};
+  k.kind = th->kind;
+  k.fixed_steps = th->bench_fixed_steps > 0 ? th->bench_fixed_steps : 0;
+  k.list_mode = w.list_mode ? 1 : 0;
+  k.n_global = (int)N;
+  k.begin = (int)begin;
+  k.n_local = (int)(end - begin);
+  k.nx = (int)std::max<size_t>(w.ax.size(), 1);
+  k.ny = (int)std::max<size_t>(w.ay.size(), 1);
+  k.nth = (int)std::max<size_t>(w.ath.size(), 1);
+  k.ay_ofs = kMaxAxis;
+  k.ath_ofs = 2 * kMaxAxis;
+  k.sim_time = th->sim_time;
+  k.sim_gran = th->sim_granularity;
+  k.ang_gran = th->angular_sim_granularity;
+  k.min_vel_x = th->min_vel_x;
+  k.max_vel_x = th->max_vel_x;
+  k.min_vel_theta = th->min_vel_theta;
+  k.min_vel_trans = th->min_vel_trans;
+  k.max_vel_trans = th->max_vel_trans;
+  k.allowed_max = in->allowed_max_linear_speed;
+  quat_to_rot(in->robot_pose, k.R);
+  for (int i = 0; i < 3; ++i) k.t[i] = in->robot_pose[i];
+  for (int v = 0; v < 8; ++v)
+    for (int j = 0; j < 3; ++j) k.cub[3 * v + j] = th->cuboid[v][j];
+  k.m = (int)ctx->plan_m;
+  quat_to_rot(ctx->plan_last, k.planR);
+  for (int i = 0; i < 3; ++i) k.planT[i] = ctx->plan_last[i];
+  k.n_critics = th->n_critics;
+  for (int m = 0; m < th->n_critics; ++m) {
+    k.ckind[m] = th->critics[m].kind;
+    k.cw[m] = th->critics[m].weight;
+    k.ctw[m] = th->critics[m].translation_weight;
+    k.cow[m] = th->critics[m].orientation_weight;
+    if (k.ckind[m] == DDDMR_CRITIC_COLLISION) k.want_collision = 1;
+    if (k.ckind[m] == DDDMR_CRITIC_COLLISION_MIN_MAX) k.want_minmax = 1;
+  }
+  k.heading_dev = in->heading_deviation;
+
+  // horizon of this tick (monotone in |v| and |w|, so the axis extremes bound it)
+  double sim_time_eff = th->sim_time;
+  int s_tick;
+  {
+    double vmax, wmax;
+    if (w.list_mode) {
+      vmax = 0; wmax = 0;
+      for (const auto& s : w.list) {
+        vmax = std::max(vmax, std::hypot((double)s.x, (double)s.y));
+        wmax = std::max(wmax, std::fabs((double)s.z));
+      }
+    } else {
+      vmax = std::hypot((double)absmax(w.ax), (double)absmax(w.ay));
+      wmax = (double)absmax(w.ath);
+    }
+    if (th->bench_fixed_steps > 0) {
+      s_tick = th->bench_fixed_steps;
+    } else if (th->kind == DDDMR_THEORY_DD_ROTATE_INPLACE) {
+      s_tick = (int)std::ceil(std::max(0.0, 6.28 / th->angular_sim_granularity)) + 1;
+      sim_time_eff = 0.0;
+    } else {
+      s_tick = (int)std::ceil(std::max(vmax * th->sim_time / th->sim_granularity,
+                                       wmax * th->sim_time / th->angular_sim_granularity)) + 1;
+    }
+    s_tick = std::max(s_tick, 1);
+  }
+  if ((uint32_t)s_tick > ctx->cfg.max_steps)
+    return fail(ctx, DDDMR_ERR_CAPACITY, "horizon of %d steps > max_steps %u", s_tick, ctx->cfg.max_steps);
+  k.max_steps = s_tick;
+
+  // trajectories per workgroup: ~one (trajectory, step) pair per lane
+  int tile = ctx->tile_override > 0 ? ctx->tile_override : kScoreThreads / s_tick;
+  tile = std::min(std::max(tile, 1), kMaxTile);
+  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m) > 60 * 1024) --tile;
+  const size_t lds = score_lds_bytes(tile, s_tick, k.m);
+  if (lds > 64 * 1024) return fail(ctx, DDDMR_ERR_CAPACITY, "horizon needs %zu bytes of LDS", lds);
+  k.tile = tile;
+
+  // ---- cloud front buffer + local costmap tile ----
+  int cidx;
+  bool pending;
+  {
+    std::lock_guard<std::mutex> lk(ctx->cloud_mu);
+    cidx = ctx->front;
+    ctx->busy = cidx;
+    pending = ctx->front_pending;
+    ctx->front_pending = false;
+  }
+  struct Unbusy {
+    dddmr_rollout_ctx* c;
+    ~Unbusy() {
+      { std::lock_guard<std::mutex> lk(c->cloud_mu); c->busy = -1; }
+      c->cloud_cv.notify_all();
+    }
+  } unbusy{ctx};
+  k.n_points = (int)ctx->cloud_n[cidx];
+  tile_extent(*th, w, k.R, k.t, sim_time_eff, k.rmin, k.rmax);
+  float cell = ctx->cell_size;
+  for (;;) {
+    k.gnx = std::max(1, (int)std::ceil((k.rmax[0] - k.rmin[0]) / cell));
+    k.gny = std::max(1, (int)std::ceil((k.rmax[1] - k.rmin[1]) / cell));
+    k.gnz = std::max(1, (int)std::ceil((k.rmax[2] - k.rmin[2]) / cell));
+    const uint64_t nc = (uint64_t)k.gnx * k.gny * k.gnz;
+    if (nc <= kCapCells) { k.n_cells = (int)nc; break; }
+    cell *= 1.5f;
+  }
+  k.inv_cell = 1.0f / cell;
+  for (int i = 0; i < 3; ++i) k.gmin[i] = k.rmin[i];
+
+  if (k.n_local > 0) {
+    // small per-tick uploads (sample axes or explicit list)
+    if (w.list_mode) {
+      std::memcpy(ctx->small_stage, w.list.data(), N * sizeof(float4));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->samples_dev, ctx->small_stage, N * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      float* a = ctx->small_stage;
+      std::memcpy(a, w.ax.data(), w.ax.size() * sizeof(float));
+      std::memcpy(a + k.ay_ofs, w.ay.data(), w.ay.size() * sizeof(float));
+      std::memcpy(a + k.ath_ofs, w.ath.data(), w.ath.size() * sizeof(float));
+      HIPCHK(ctx, hipMemcpyAsync(ctx->axes_dev, a, 3 * kMaxAxis * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
+  if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
+
+  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  const int bin_blocks = std::max(1, std::min(2048, (k.n_points + 255) / 256));
+  if (k.n_points > 0)
+    hipLaunchKernelGGL(k_bin_count, dim3(bin_blocks), dim3(256), 0, ctx->stream, k, ctx->cloud_dev[cidx],
+                       ctx->cell_count, ctx->pt_slot);
+  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, ctx->stream, k, ctx->cell_count, ctx->cell_start,
+                     ctx->best_key, ctx->overflow);
+  if (k.n_points > 0)
+    hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks), dim3(256), 0, ctx->stream, k, ctx->cloud_dev[cidx],
+                       ctx->pt_slot, ctx->cell_start, ctx->sorted);
+  if (k.n_local > 0) {
+    const int wgs = (k.n_local + tile - 1) / tile;
+    hipLaunchKernelGGL(k_score, dim3(wgs), dim3(kScoreThreads), lds, ctx->stream, k, ctx->axes_dev,
+                       ctx->samples_dev, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
+                       ctx->samples_out, ctx->best_key, ctx->overflow);
+  }
+  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, ctx->stream, k, ctx->best_key, ctx->costs,
+                     ctx->samples_out, ctx->cell_start, ctx->overflow, ctx->result_dev);
+  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  HIPCHK(ctx, hipMemcpyAsync(ctx->result_host, ctx->result_dev, sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+
+  const DevResult r = *ctx->result_host;
+  ctx->last = k;
+  ctx->have_last = true;
+  if (r.overflow)
+    return fail(ctx, DDDMR_ERR_CAPACITY, "a trajectory needed more than %d steps", s_tick);
+  out->device_ms = ms;
+  out->n_points_binned = r.n_binned;
+  out->key = r.key;
+  if (r.index >= 0) {
+    out->planner_state = DDDMR_TRAJECTORY_FOUND;
+    out->best_index = r.index;
+    out->best_cost = r.cost;
+    out->vx = r.vx; out->vy = r.vy; out->wz = r.wz;
+  }
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key, dddmr_rollout_result* inout) {
+  if (!ctx || !inout) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (!ctx->have_last) return fail(ctx, DDDMR_ERR_STATE, "resolve before any tick");
+  inout->key = reduced_key;
+  const int32_t idx = key_index(reduced_key);
+  if (idx < 0) {
+    inout->planner_state = DDDMR_ALL_TRAJECTORIES_FAIL;
+    inout->best_index = -1;
+    inout->best_cost = -1.0;
+    inout->vx = inout->vy = inout->wz = 0.0;
+    return DDDMR_OK;
+  }
+  if (idx >= ctx->last.n_global) return fail(ctx, DDDMR_ERR_BAD_ARG, "resolve: index %d out of range", idx);
+  // samples are a closed-form grid (or the tick's explicit list): every rank can
+  // recompute the winner's command from its index
+  const Window& w = ctx->last_window;
+  float vx, vy, wz;
+  if (w.list_mode) {
+    vx = w.list[idx].x; vy = w.list[idx].y; wz = w.list[idx].z;
+  } else {
+    const int nth = (int)w.ath.size(), ny = (int)w.ay.size();
+    vx = w.ax[(idx / nth) / ny];
+    vy = w.ay[(idx / nth) % ny];
+    wz = w.ath[idx % nth];
+  }
+  inout->planner_state = DDDMR_TRAJECTORY_FOUND;
+  inout->best_index = idx;
+  inout->vx = vx; inout->vy = vy; inout->wz = wz;
+  const int li = idx - ctx->last.begin;
+  if (li >= 0 && li < ctx->last.n_local) {
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    double c = 0;
+    HIPCHK(ctx, hipMemcpy(&c, ctx->costs + li, sizeof(double), hipMemcpyDeviceToHost));
+    inout->best_cost = c;
+  } else {
+    // winner lives on another rank: the key carries the cost's top 40 bits
+    union { double d; uint64_t u; } cv;
+    cv.u = (uint64_t)reduced_key & ~((1ull << kKeyIndexBits) - 1);
+    inout->best_cost = cv.d;
+  }
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg) {
+  if (!ctx || !dbg) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (!ctx->have_last) return fail(ctx, DDDMR_ERR_STATE, "get_debug before any tick");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = (size_t)ctx->last.n_local;
+  if (n == 0) return DDDMR_OK;
+  if (dbg->costs) HIPCHK(ctx, hipMemcpy(dbg->costs, ctx->costs, n * sizeof(double), hipMemcpyDeviceToHost));
+  if (dbg->steps) HIPCHK(ctx, hipMemcpy(dbg->steps, ctx->steps, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (dbg->samples) {
+    std::vector<float4> tmp(n);
+    HIPCHK(ctx, hipMemcpy(tmp.data(), ctx->samples_out, n * sizeof(float4), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) {
+      dbg->samples[3 * i + 0] = tmp[i].x;
+      dbg->samples[3 * i + 1] = tmp[i].y;
+      dbg->samples[3 * i + 2] = tmp[i].z;
+    }
+  }
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out, size_t capacity, size_t* n_poses) {
+  if (!ctx || !n_poses) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (!ctx->have_last) return fail(ctx, DDDMR_ERR_STATE, "get_best_poses before any tick");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const int32_t idx = ctx->result_host->index;
+  *n_poses = 0;
+  if (idx < 0) return DDDMR_OK;
+  const int li = idx - ctx->last.begin;
+  if (li < 0 || li >= ctx->last.n_local) return DDDMR_OK;  // winner is on another rank
+  int32_t ns = 0;
+  HIPCHK(ctx, hipMemcpy(&ns, ctx->steps + li, sizeof(int32_t), hipMemcpyDeviceToHost));
+  *n_poses = (size_t)ns;
+  if (!poses_out) return DDDMR_OK;
+  if (capacity < (size_t)ns) return fail(ctx, DDDMR_ERR_CAPACITY, "get_best_poses: capacity %zu < %d", capacity, ns);
+  hipLaunchKernelGGL(k_trajectory_poses, dim3(1), dim3(64), 0, ctx->stream, ctx->last, li, ctx->samples_out,
+                     ctx->steps, ctx->poses_dev);
+  HIPCHK(ctx, hipMemcpyAsync(poses_out, ctx->poses_dev, (size_t)ns * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return DDDMR_OK;
+}
+
+}  // extern "C"
