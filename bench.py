@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- scored trajectories/sec of the local-planner tick on MI355X.
+
+A "step" is one control tick over one batch of synthetic input: local costmap
+binning + fused rollout + all critics + argmin (+ one 8-byte min all-reduce when
+N > 1), with the cloud already resident in HBM (set_cloud is outside the timed
+region) and the chosen cmd_vel delivered to the host every tick.
+
+Workload: BASELINE.json configs[1] ("C2": 4096 trajectories x 50 steps vs a
+100k-point cloud) per GPU.  Multi-GPU is weak scaling: the global batch is
+4096*N samples (x-axis of the sample grid 16*N long), rank r scores the
+contiguous index range [4096 r, 4096 (r+1)), one all-reduce picks the winner.
+`--workload C3|C4` selects the other configurations (C4 = 65536 samples, strong).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from dddmr_navigation_amd import scenes, configs, sharding, _capi as K
+    from dddmr_navigation_amd.local_planner import LocalPlanner
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the rollout engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # ---- workload ----
+    sc = scenes.bench_scene(args.workload)
+    theory = sc.theory
+    scaling = "weak"
+    if args.workload == "C2":
+        theory.linear_x_sample = 16.0 * world          # 4096 samples per GPU
+    elif args.workload == "C4":
+        scaling = "strong"
+    name = theory.name.decode()
+    b = configs.BENCH[args.workload]
+    n_steps_traj = b["steps"]
+
+    lp = LocalPlanner([theory], device=local_rank, max_points=len(sc.cloud), max_trajectories=1 << 20,
+                      rank=rank, world_size=world)
+    lp.set_cloud(sc.cloud)            # inputs resident in HBM before the timed region
+    lp.setPlan(sc.plan)
+
+    key_t = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        res = lp.tick(name, sc.tick)
+        if world > 1:
+            key_t.fill_(res.key)
+            dist.all_reduce(key_t, op=dist.ReduceOp.MIN)     # RCCL over xGMI, 8 bytes
+            res = lp.resolve(int(key_t.item()))
+        return res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = step()
+    fence()
+    dev_ms, score_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+        dev_ms.append(lp.last_result.device_ms)
+        score_ms.append(lp.last_result.score_ms)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        elapsed = float(et.item())
+
+    n_global = int(lp.last_result.n_samples)
+    n_local = int(lp.last_result.n_local)
+    value = n_global * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        import oracle
+        # ---- roofline of the dominant kernel (k_score), SURVEY.md 8(d) ----
+        # algorithmic bytes of this rank's launch = sum over the steps the
+        # reference evaluates of (32 + 16 k) + 32 M + 32 N_local, k = radius-search
+        # result sizes, counted by the oracle on the very same inputs.
+        b0, e0 = sharding.shard_range(0, world, n_global)
+        o = oracle.tick(theory, sc.cloud, sc.plan, sc.tick, begin=b0, end=e0, n_threads=os.cpu_count() or 1)
+        r = o.result
+        units = int(r.steps_total)                         # trajectory-steps per launch
+        alg_bytes = 32 * int(r.steps_eval) + 16 * int(r.k_sum) + 32 * len(sc.plan) + 32 * n_local
+        per_unit = alg_bytes / max(units, 1)
+        k_ms = float(np.mean(score_ms))
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.workload, {}).get("k_score_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_score", "achieved": round(achieved, 2), "peak": 8000.0,
+                    "unit": "GB/s", "frac": round(achieved / 8000.0, 4), "traffic": traffic,
+                    "alg_bytes_per_launch": alg_bytes, "units_per_launch": units,
+                    "bytes_per_unit": round(per_unit, 2), "kernel_ms": round(k_ms, 5),
+                    "tick_device_ms": round(float(np.mean(dev_ms)), 5),
+                    "tick_alg_bytes": alg_bytes + 16 * len(sc.cloud)}
+        # parity spot check of what was just timed
+        parity_ok = bool(world > 1 or (res.best_index == r.best_index and abs(res.vx - r.vx) <= 1e-4
+                                       and abs(res.vy - r.vy) <= 1e-4 and abs(res.wz - r.wz) <= 1e-4))
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            # the oracle ("port"), 1 core like the reference's loops, bounded sample
+            n_ticks, t_cpu = 0, 0.0
+            while t_cpu < args.cpu_seconds:
+                t1 = time.perf_counter()
+                oracle.tick(theory, sc.cloud, sc.plan, sc.tick, n_threads=1)
+                t_cpu += time.perf_counter() - t1
+                n_ticks += 1
+            ncpu = os.cpu_count() or 1
+            t1 = time.perf_counter()
+            oracle.tick(theory, sc.cloud, sc.plan, sc.tick, n_threads=ncpu)
+            t_all = time.perf_counter() - t1
+            cpu = {"value": round(n_global * n_ticks / t_cpu, 1), "unit": "trajectories/s", "cores": 1,
+                   "kind": "port", "sample": f"{n_ticks} full {args.workload} ticks ({n_global} traj x {n_steps_traj} steps, "
+                   f"kd-tree build included), {t_cpu:.1f} s", "all_cores_value": round(n_global / t_all, 1),
+                   "all_cores": ncpu}
+        out = {
+            "metric": "scored trajectories/sec (N_traj x N_steps)", "value": round(value, 1),
+            "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {n_global} trajectories x {n_steps_traj} steps vs "
+                                   f"{len(sc.cloud)}-point cloud, {len(sc.plan)}-pose prune plan, shipped critic stack",
+                       "trajectories_per_gpu": n_local, "steps_per_trajectory": n_steps_traj,
+                       "trajectory_steps_per_s": round(value * n_steps_traj, 1),
+                       "parallelism": f"traj-shard x{world}" if world > 1 else "single",
+                       "cmd_vel": [res.vx, res.vy, res.wz], "best_index": int(res.best_index),
+                       "cmd_vel_matches_oracle": parity_ok},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+    lp.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

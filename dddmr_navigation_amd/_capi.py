@@ -131,7 +131,7 @@ class RolloutResult(C.Structure):
         ("n_points_binned", C.c_uint32),
         ("key", C.c_int64),
         ("device_ms", C.c_float),
-        ("reserved", C.c_float),
+        ("score_ms", C.c_float),
     ]
 
 

@@ -152,7 +152,7 @@ struct dddmr_rollout_ctx {
   std::vector<dddmr_theory_config> theories;
   int device = 0;
   hipStream_t stream = nullptr, copy_stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, cloud_ready[2] = {nullptr, nullptr};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr, cloud_ready[2] = {nullptr, nullptr};
 
   // device memory
   float4* cloud_dev[2] = {nullptr, nullptr};
@@ -315,6 +315,8 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   if (ctx->result_host) (void)hipHostFree(ctx->result_host);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->evs0) (void)hipEventDestroy(ctx->evs0);
+  if (ctx->evs1) (void)hipEventDestroy(ctx->evs1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
   delete ctx;
@@ -354,6 +356,8 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
     HIPCHK(ctx, hipEventCreate(&ctx->ev1));
+    HIPCHK(ctx, hipEventCreate(&ctx->evs0));
+    HIPCHK(ctx, hipEventCreate(&ctx->evs1));
     const size_t P = cfg->max_points, N = cfg->max_trajectories;
     const size_t plan_cap = std::max<uint32_t>(cfg->max_plan_poses, 1);
     for (int i = 0; i < 2; ++i) {
@@ -674,12 +678,14 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   if (k.n_points > 0)
     hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks), dim3(256), 0, ctx->stream, k, ctx->cloud_dev[cidx],
                        ctx->pt_slot, ctx->cell_start, ctx->sorted);
+  HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
   if (k.n_local > 0) {
     const int wgs = (k.n_local + tile - 1) / tile;
     hipLaunchKernelGGL(k_score, dim3(wgs), dim3(kScoreThreads), lds, ctx->stream, k, ctx->axes_dev,
                        ctx->samples_dev, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
                        ctx->samples_out, ctx->best_key, ctx->overflow);
   }
+  HIPCHK(ctx, hipEventRecord(ctx->evs1, ctx->stream));
   hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, ctx->stream, k, ctx->best_key, ctx->costs,
                      ctx->samples_out, ctx->cell_start, ctx->overflow, ctx->result_dev);
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -688,6 +694,8 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   HIPCHK(ctx, hipGetLastError());
   float ms = 0.f;
   HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  float score_ms = 0.f;
+  HIPCHK(ctx, hipEventElapsedTime(&score_ms, ctx->evs0, ctx->evs1));
 
   const DevResult r = *ctx->result_host;
   ctx->last = k;
@@ -695,6 +703,7 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   if (r.overflow)
     return fail(ctx, DDDMR_ERR_CAPACITY, "a trajectory needed more than %d steps", s_tick);
   out->device_ms = ms;
+  out->score_ms = score_ms;
   out->n_points_binned = r.n_binned;
   out->key = r.key;
   if (r.index >= 0) {

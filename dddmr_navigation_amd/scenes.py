@@ -233,3 +233,35 @@ def playground_scene(goal=(3.0, 1.0), sim_time: float = 5.0) -> Scene:
                       [0.70, 0.70, 0.2, 0], [0.90, 0.50, 0.2, 0]], dtype=np.float32)
     return Scene("playground", configs.dd_simple_shipped(sim_time=sim_time), cloud,
                  straight_plan(goal), tick_input(twist=(0.4, 0.0, 0.0)))
+
+
+def lidar_scan(cloud_xyz: np.ndarray, sensor_xyz=(0.0, 0.0, 0.5), seed: int = 0, rings: int = 16,
+               azimuths: int = 1800, fov_deg: float = 15.0, sigma: float = 0.01,
+               max_range: float = 30.0) -> np.ndarray:
+    """C5: the scene seen by a 16-ring, 1800-azimuth spinning LiDAR at
+    sensor_xyz (sensor axes = global axes), +-15 deg vertical FOV, gaussian
+    range noise.  Spherical z-buffer over the scene cloud: per (ring, azimuth)
+    bin the nearest point survives.  Returns [K,3] float32 in the SENSOR frame."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rel = cloud_xyz[:, :3].astype(np.float64) - np.asarray(sensor_xyz, dtype=np.float64)
+    rng_xy = np.hypot(rel[:, 0], rel[:, 1])
+    dist = np.sqrt(rng_xy ** 2 + rel[:, 2] ** 2)
+    el = np.degrees(np.arctan2(rel[:, 2], rng_xy))
+    az = np.arctan2(rel[:, 1], rel[:, 0])
+    ok = (np.abs(el) <= fov_deg) & (dist > 0.3) & (dist < max_range)
+    rel, dist, el, az = rel[ok], dist[ok], el[ok], az[ok]
+    ring = np.clip(np.round((el + fov_deg) / (2 * fov_deg) * (rings - 1)).astype(np.int64), 0, rings - 1)
+    # a beam only returns if the point is close to the ring's elevation
+    ring_el = -fov_deg + ring * (2 * fov_deg / (rings - 1))
+    near = np.abs(el - ring_el) <= 0.5
+    azb = np.floor((az + np.pi) / (2 * np.pi) * azimuths).astype(np.int64) % azimuths
+    key = ring * azimuths + azb
+    key, rel, dist = key[near], rel[near], dist[near]
+    order = np.lexsort((dist, key))
+    key, rel, dist = key[order], rel[order], dist[order]
+    first = np.ones(len(key), dtype=bool)
+    first[1:] = key[1:] != key[:-1]
+    rel, dist = rel[first], dist[first]
+    noisy = dist + rng.normal(0.0, sigma, size=dist.shape)
+    pts = rel * (noisy / dist)[:, None]
+    return pts.astype(np.float32)

@@ -188,7 +188,7 @@ typedef struct {
   /* packed argmin key of this shard, see dddmr_rollout_pack_key */
   int64_t key;
   float device_ms;           /* HIP-event time of the tick's kernels */
-  float reserved;
+  float score_ms;            /* HIP-event time of the fused rollout+critics kernel alone */
 } dddmr_rollout_result;
 
 /* Optional per-trajectory outputs of the last tick (caller-allocated). */

@@ -801,6 +801,81 @@ int oracle_radius_count(const float* xyz, size_t n_points, size_t stride_bytes, 
   return 0;
 }
 
+// --------------------------------------------------------------------------
+// Local-mode perception feed: MultiLayerSpinningLidar::cbSensor
+// (dddmr_perception_3d/plugins/multilayer_spinning_lidar.cpp:177-281), stitcher
+// off.  Third-party arithmetic restated from PCL 1.15: transformPointCloud
+// (double multiply-add -> float), PassThrough (keep min <= v <= max, drop
+// non-finite), VoxelGrid::applyFilter with downsample_all_data (voxel =
+// floor(p * inverse_leaf) - min_b, points sorted by voxel index, centroid by
+// CentroidPoint = float accumulation / n).  PCL's std::sort is unstable, so the
+// summation order inside a voxel is unspecified there; here it is input order.
+// Output order = ascending voxel index, like PCL.
+// --------------------------------------------------------------------------
+int oracle_feed(const float* scan, size_t n, size_t stride_bytes, const double T_base_sensor[7],
+                const double T_gbl_base[7], double window, double height, float* out_xyz,
+                size_t capacity, size_t* n_out) {
+  const size_t sf = stride_bytes / sizeof(float);
+  const Affine b2s = transform_to_eigen(T_base_sensor);
+  const Affine g2b = transform_to_eigen(T_gbl_base);
+  std::vector<F3> pts;
+  pts.reserve(n);
+  const float lim = (float)window, zmax = (float)height;
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = scan + i * sf;
+    if (!std::isfinite(p[0]) || !std::isfinite(p[1]) || !std::isfinite(p[2])) continue;
+    F3 q;
+    q.x = (float)(b2s.l[0][0] * p[0] + b2s.l[0][1] * p[1] + b2s.l[0][2] * p[2] + b2s.t[0]);
+    q.y = (float)(b2s.l[1][0] * p[0] + b2s.l[1][1] * p[1] + b2s.l[1][2] * p[2] + b2s.t[1]);
+    q.z = (float)(b2s.l[2][0] * p[0] + b2s.l[2][1] * p[1] + b2s.l[2][2] * p[2] + b2s.t[2]);
+    if (q.x < -lim || q.x > lim) continue;   // PassThrough "x"
+    if (q.y < -lim || q.y > lim) continue;   // PassThrough "y" (same limits, :246-247)
+    if (q.z < 0.0f || q.z > zmax) continue;  // PassThrough "z"
+    pts.push_back(q);
+  }
+  *n_out = 0;
+  if (pts.empty()) return 0;
+  const float inv = 1.0f / 0.1f;  // inverse_leaf_size_
+  F3 mn = pts[0], mx = pts[0];
+  for (const F3& q : pts) {
+    mn.x = std::min(mn.x, q.x); mn.y = std::min(mn.y, q.y); mn.z = std::min(mn.z, q.z);
+    mx.x = std::max(mx.x, q.x); mx.y = std::max(mx.y, q.y); mx.z = std::max(mx.z, q.z);
+  }
+  const int minb[3] = {(int)std::floor(mn.x * inv), (int)std::floor(mn.y * inv), (int)std::floor(mn.z * inv)};
+  const int maxb[3] = {(int)std::floor(mx.x * inv), (int)std::floor(mx.y * inv), (int)std::floor(mx.z * inv)};
+  const int64_t d0 = maxb[0] - minb[0] + 1, d1 = maxb[1] - minb[1] + 1;
+  std::vector<std::pair<int64_t, uint32_t>> order(pts.size());
+  for (size_t i = 0; i < pts.size(); ++i) {
+    const int64_t i0 = (int64_t)std::floor(pts[i].x * inv) - minb[0];
+    const int64_t i1 = (int64_t)std::floor(pts[i].y * inv) - minb[1];
+    const int64_t i2 = (int64_t)std::floor(pts[i].z * inv) - minb[2];
+    order[i] = {i0 + i1 * d0 + i2 * d0 * d1, (uint32_t)i};
+  }
+  std::stable_sort(order.begin(), order.end(),
+                   [](const auto& a, const auto& b) { return a.first < b.first; });
+  size_t out = 0;
+  for (size_t i = 0; i < order.size();) {
+    size_t j = i;
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    while (j < order.size() && order[j].first == order[i].first) {
+      const F3& q = pts[order[j].second];
+      sx += q.x; sy += q.y; sz += q.z;
+      ++j;
+    }
+    const float cnt = (float)(j - i);
+    const float cx = sx / cnt, cy = sy / cnt, cz = sz / cnt;
+    if (out < capacity && out_xyz) {
+      out_xyz[3 * out + 0] = (float)(g2b.l[0][0] * cx + g2b.l[0][1] * cy + g2b.l[0][2] * cz + g2b.t[0]);
+      out_xyz[3 * out + 1] = (float)(g2b.l[1][0] * cx + g2b.l[1][1] * cy + g2b.l[1][2] * cz + g2b.t[1]);
+      out_xyz[3 * out + 2] = (float)(g2b.l[2][0] * cx + g2b.l[2][1] * cy + g2b.l[2][2] * cz + g2b.t[2]);
+    }
+    ++out;
+    i = j;
+  }
+  *n_out = out;
+  return 0;
+}
+
 // One control tick: local_planner.cpp:535-587 + getBestTrajectory (:447-480).
 // [begin,end) selects a contiguous range of the global sample list (sharding
 // tests, bounded CPU-baseline samples); pass 0,UINT32_MAX for everything.

@@ -46,6 +46,10 @@ int oracle_tick(const dddmr_theory_config* theory, const float* cloud, size_t n_
                 oracle_result* out, double* costs, int32_t* steps, float* samples_out,
                 double* last_poses, float* min_margin);
 
+int oracle_feed(const float* scan, size_t n, size_t stride_bytes, const double T_base_sensor[7],
+                const double T_gbl_base[7], double window, double height, float* out_xyz,
+                size_t capacity, size_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

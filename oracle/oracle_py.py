@@ -56,6 +56,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
                                 C.c_int, C.POINTER(OracleResult), C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_void_p]
     lib.oracle_tick.restype = C.c_int
+    lib.oracle_feed.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.c_double, C.c_double, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.oracle_feed.restype = C.c_int
     _lib = lib
     return lib
 
@@ -136,3 +139,16 @@ def tick(theory: K.TheoryConfig, cloud: np.ndarray, plan: np.ndarray, tick_in: K
     if rc != 0:
         raise RuntimeError(f"oracle_tick failed: {rc}")
     return TickOut(res, costs[:nl], steps[:nl], smp[:nl], lastp[:nl], None if mm is None else mm[:nl])
+
+
+def feed(scan_xyz: np.ndarray, T_base_sensor, T_gbl_base, window: float, height: float) -> np.ndarray:
+    """cbSensor local-mode feed -> [K,3] float32 in the global frame, voxel-index order."""
+    lib = load()
+    scan = np.ascontiguousarray(scan_xyz, dtype=np.float32)
+    tbs = (C.c_double * 7)(*[float(v) for v in T_base_sensor])
+    tgb = (C.c_double * 7)(*[float(v) for v in T_gbl_base])
+    out = np.zeros((max(len(scan), 1), 3), dtype=np.float32)
+    n = C.c_size_t(0)
+    stride = scan.strides[0] if len(scan) else 12
+    lib.oracle_feed(_ptr(scan), len(scan), stride, tbs, tgb, window, height, _ptr(out), len(out), C.byref(n))
+    return out[: n.value].copy()

@@ -1,0 +1,50 @@
+"""Generates tests/golden/*.npz from the CPU oracle (oracle/oracle.cpp).
+
+PARITY UNPINNED: the reference holds no golden vectors for this path and cannot
+be built here, so these vectors are outputs of the build's own restatement of
+the cited reference source, frozen so that (a) the oracle cannot drift silently
+and (b) the HIP path is checked against bytes committed to the repo.  Inputs
+are the deterministic scenes of dddmr_navigation_amd/scenes.py (F1 = the
+reference's playground scenario, local_planner_play_ground_node.cpp:206-298).
+
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from dddmr_navigation_amd import scenes  # noqa: E402
+import oracle  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def dump(name, sc, **kw):
+    o = oracle.tick(sc.theory, sc.cloud, sc.plan, sc.tick, n_threads=8, want_margin=True, **kw)
+    r = o.result
+    np.savez_compressed(
+        os.path.join(HERE, name + ".npz"),
+        costs=o.costs, steps=o.steps, samples=o.samples, min_margin=o.min_margin,
+        summary=np.array([r.planner_state, r.best_index, r.n_samples, r.n_generated], dtype=np.int64),
+        best=np.array([r.best_cost, r.vx, r.vy, r.wz], dtype=np.float64),
+        counters=np.array([r.k_sum, r.steps_eval, r.steps_total], dtype=np.uint64),
+    )
+    print(f"{name}: N={r.n_samples} best={r.best_index} cost={r.best_cost:.9f} k_sum={r.k_sum} "
+          f"steps_eval={r.steps_eval} steps_total={r.steps_total}")
+
+
+def main():
+    for goal, tag in (((3.0, 1.0), "L"), ((3.0, -1.0), "R")):
+        for st, stag in ((5.0, "st5"), (2.0, "st2")):
+            dump(f"F1_playground_{tag}_{stag}", scenes.playground_scene(goal, st))
+    dump("F6_C1", scenes.bench_scene("C1"))
+    dump("F7_C2", scenes.bench_scene("C2"))
+    dump("F8_C3", scenes.bench_scene("C3"))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,309 @@
+"""CPU tests of the oracle: known answers derivable by hand from the reference
+source, independent cross-checks of its neighbour search, critic
+unit cases (F2), tie-break (F3), 3-D pose (F4), theory counts (F5) and the
+frozen golden vectors (F1, F6-F8)."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from dddmr_navigation_amd import _capi as K, configs, scenes
+import oracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def ident_tick(twist=(0.4, 0.0, 0.0), **kw):
+    return scenes.tick_input(twist=twist, **kw)
+
+
+# ---- a2: VelocityIterator (velocity_iterator.h:44-69) -----------------------
+def test_velocity_iterator_inserts_zero_and_forces_max():
+    v = oracle.velocity_iterator(-0.3, 0.3, 10)
+    assert len(v) == 11                      # 9 stepped + inserted 0 + max
+    assert v[0] == -0.3 and v[-1] == 0.3
+    assert 0.0 in v
+    assert np.all(np.diff(v) > 0)
+    v = oracle.velocity_iterator(0.2, 0.5, 5)
+    assert len(v) == 5 and v[0] == 0.2 and v[-1] == 0.5
+    assert list(oracle.velocity_iterator(0.3, 0.3, 7)) == [0.3]       # min == max
+    assert len(oracle.velocity_iterator(0.0, 1.0, 1)) == 2             # max(2, n)
+    assert len(oracle.velocity_iterator(-0.3, 0.3, 10, no_zero_insert=True)) == 10
+
+
+# ---- a3/a4 known answers: playground and shipped DD configs ------------------
+def test_playground_known_answers():
+    sc = scenes.playground_scene((3.0, 1.0), 5.0)
+    smp = oracle.samples(sc.theory, sc.tick)
+    assert len(smp) == 55
+    xs = np.unique(smp[:, 0])
+    np.testing.assert_allclose(xs, [0.2, 0.275, 0.35, 0.425, 0.5], rtol=1e-6)
+    assert len(np.unique(smp[:, 2])) == 11 and 0.0 in smp[:, 2]
+    # x-major, theta-minor order
+    assert np.all(smp[:11, 0] == smp[0, 0]) and np.all(np.diff(smp[:11, 2]) > 0)
+    o = oracle.tick(sc.theory, sc.cloud, sc.plan, sc.tick)
+    assert o.steps.min() == 21 and o.steps.max() == 61 and int(o.steps.sum()) == 2363
+    # 0.2f * 5 / 0.05 = 20.0000003 -> ceil 21 (float32 sample promoted to double)
+    assert o.steps[5] == 21
+    sc2 = scenes.playground_scene((3.0, 1.0), 2.0)
+    o2 = oracle.tick(sc2.theory, sc2.cloud, sc2.plan, sc2.tick)
+    assert o2.steps.min() == 9 and o2.steps.max() == 25 and int(o2.steps.sum()) == 967
+
+
+def test_first_pose_is_after_one_step():
+    sc = scenes.playground_scene()
+    poses, cub, mm = oracle.generate(sc.theory, sc.tick, (0.5, 0.0, 0.0))
+    assert len(poses) == 50
+    dt = 5.0 / 50
+    assert poses[0, 0] == pytest.approx(0.5 * dt, rel=1e-6)      # first recorded pose is t = dt
+    assert poses[-1, 0] == pytest.approx(2.5, rel=1e-5)
+    # cuboid vertex order blb,brb,blt,flb,...: vertex 0 = pose + (-0.35, 0.36, 0)
+    np.testing.assert_allclose(cub[0, 0], [0.5 * dt - 0.35, 0.36, 0.0], atol=1e-6)
+    np.testing.assert_allclose(cub[0, 3], [0.5 * dt + 0.42, 0.36, 0.0], atol=1e-6)
+    np.testing.assert_allclose(mm[0, 0], cub[0].min(0))
+    np.testing.assert_allclose(mm[0, 1], cub[0].max(0))
+
+
+def test_generation_gates():
+    sc = scenes.playground_scene()
+    # slower than min_vel_x AND min_vel_theta -> rejected (dd_simple...cpp:364-367)
+    assert len(oracle.generate(sc.theory, sc.tick, (0.05, 0.0, 0.05))[0]) == 0
+    # one of the two minima reached -> generated
+    assert len(oracle.generate(sc.theory, sc.tick, (0.05, 0.0, 0.3))[0]) > 0
+    # above max_vel_x -> rejected (:369-371)
+    assert len(oracle.generate(sc.theory, sc.tick, (1.2, 0.0, 0.0))[0]) == 0
+
+
+# ---- F5: omni grid and rotate-in-place --------------------------------------
+def test_omni_shipped_grid_count_and_order():
+    th = configs.omni_simple_shipped()
+    ti = scenes.tick_input(twist=(0.0, 0.0, 0.0))
+    smp = oracle.samples(th, ti)
+    # window [-0.2,0.2] x [-0.2,0.2] x [-0.3,0.3]; 5(+0 already present) x 5 x 11
+    nx, ny, nth = len(np.unique(smp[:, 0])), len(np.unique(smp[:, 1])), len(np.unique(smp[:, 2]))
+    assert len(smp) == nx * ny * nth
+    assert nth == 11
+    # x-outer, y, theta-inner
+    assert np.all(smp[:nth, 0] == smp[0, 0]) and np.all(smp[:nth, 1] == smp[0, 1])
+    assert smp[nth, 1] != smp[0, 1] and smp[nth, 0] == smp[0, 0]
+
+
+@pytest.mark.parametrize("gran,expect", [(0.05, 126), (0.025, 252)])
+def test_rotate_inplace_steps(gran, expect):
+    th = configs.rotate_inplace_shipped(angular_sim_granularity=gran)
+    sc = scenes.playground_scene()
+    o = oracle.tick(th, sc.cloud, sc.plan, sc.tick)
+    assert o.result.n_samples == 2
+    assert list(o.steps) == [expect, expect]
+    np.testing.assert_allclose(o.samples[:, 2], [0.5, -0.5])
+
+
+# ---- neighbour search cross-checks ------------------------------------------
+def test_kdtree_matches_bruteforce_and_scipy():
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(7)
+    cloud = rng.uniform(-3, 3, size=(20000, 3)).astype(np.float32)
+    q = rng.uniform(-3, 3, size=(300, 3)).astype(np.float32)
+    counts = oracle.radius_count(cloud, q, 1.0)
+    # FLANN float distance, strict <
+    d2 = ((cloud[None, :, 0] - q[:, None, 0]) ** 2 + (cloud[None, :, 1] - q[:, None, 1]) ** 2).astype(np.float32)
+    d2 = (d2 + (cloud[None, :, 2] - q[:, None, 2]) ** 2).astype(np.float32)
+    np.testing.assert_array_equal(counts, (d2 < np.float32(1.0)).sum(1))
+    tree = cKDTree(cloud.astype(np.float64))
+    sc_counts = np.array([len(x) for x in tree.query_ball_point(q.astype(np.float64), 1.0)])
+    assert np.abs(sc_counts - counts).max() <= 2      # only boundary rounding may differ
+
+
+# ---- F2: critics in isolation -----------------------------------------------
+def one_critic_theory(kind, **kw):
+    c = configs.critic(kind, **kw)
+    return configs.dd_simple_shipped(sim_time=2.0, critics=[c])
+
+
+def wall_cloud(x, n=6):
+    ys = np.linspace(-0.2, 0.2, n)
+    return np.array([[x, y, 0.3, 0.0] for y in ys], dtype=np.float32)
+
+
+def test_collision_critic_inside_outside_and_small_cloud():
+    th = one_critic_theory(K.CRITIC_COLLISION)
+    plan = scenes.straight_plan((3.0, 0.0))
+    ti = ident_tick()
+    # robot drives +x up to 0.5*2 = 1.0 m; front face at pose.x + 0.42
+    o = oracle.tick(th, wall_cloud(1.30), plan, ti)      # straight v=0.5: front reaches 1.42
+    straight = int(np.nonzero((o.samples[:, 0] == 0.5) & (o.samples[:, 2] == 0.0))[0][0])
+    assert o.costs[straight] == -1.0
+    o = oracle.tick(th, wall_cloud(1.45), plan, ti)      # 3 cm beyond the last front face
+    assert o.costs[straight] == 0.0
+    # < 5 points: the critic returns 0 even with a point inside the box
+    o = oracle.tick(th, wall_cloud(1.30, n=4), plan, ti)
+    assert np.all(o.costs == 0.0)
+    # point above the 0.6 m tall box never collides
+    hi = wall_cloud(1.0); hi[:, 2] = 0.75
+    assert np.all(oracle.tick(th, hi, plan, ti).costs == 0.0)
+
+
+def test_collision_min_max_is_conservative():
+    plan = scenes.straight_plan((3.0, 0.0))
+    ti = ident_tick()
+    # a point just outside a rotated box's corner is inside its world AABB
+    cloud = np.array([[0.9, 0.55, 0.3, 0]] * 5, dtype=np.float32)
+    a = oracle.tick(one_critic_theory(K.CRITIC_COLLISION), cloud, plan, ti)
+    b = oracle.tick(one_critic_theory(K.CRITIC_COLLISION_MIN_MAX), cloud, plan, ti)
+    assert np.all(b.costs[a.costs == -1.0] == -1.0)
+    assert (b.costs == -1.0).sum() > (a.costs == -1.0).sum()
+
+
+def test_path_critics_short_plan_and_values():
+    ti = ident_tick()
+    cloud = np.zeros((0, 4), dtype=np.float32)
+    short = scenes.straight_plan((3.0, 0.0))[:2]
+    assert np.all(oracle.tick(one_critic_theory(K.CRITIC_STICK_PATH), cloud, short, ti).costs == 10.0)
+    assert np.all(oracle.tick(one_critic_theory(K.CRITIC_TOWARD_GLOBAL_PLAN), cloud, short, ti).costs == 10.0)
+    # pure pursuit: empty plan -> -4
+    assert np.all(oracle.tick(one_critic_theory(K.CRITIC_PURE_PURSUIT), cloud, short[:0], ti).costs == -4.0)
+    # straight trajectory on a straight plan: stick = sum(NN dist)/M (divided by plan size, not steps)
+    plan = scenes.straight_plan((3.0, 0.0))        # 20 poses, 0.15 m apart
+    o = oracle.tick(one_critic_theory(K.CRITIC_STICK_PATH), cloud, plan, ti)
+    i = int(np.nonzero((o.samples[:, 0] == 0.5) & (o.samples[:, 2] == 0.0))[0][0])
+    poses, _, _ = oracle.generate(configs.dd_simple_shipped(), ti, o.samples[i])
+    px = poses[:, 0].astype(np.float32)
+    d = np.abs(px[:, None] - plan[None, :, 0].astype(np.float32)).min(1)
+    assert o.costs[i] == pytest.approx(float(d.astype(np.float64).sum()) / 20.0, rel=1e-6)
+    # toward_global_plan: weight * distance of the LAST pose
+    o2 = oracle.tick(one_critic_theory(K.CRITIC_TOWARD_GLOBAL_PLAN, weight=2.5), cloud, plan, ti)
+    assert o2.costs[i] == pytest.approx(2.5 * float(d[-1]), rel=1e-6)
+
+
+def test_pure_pursuit_fold_and_distance():
+    ti = ident_tick()
+    cloud = np.zeros((0, 4), dtype=np.float32)
+    th = one_critic_theory(K.CRITIC_PURE_PURSUIT, translation_weight=1.0, orientation_weight=1.0)
+    for yaw_plan in (0.3, -0.3):
+        plan = scenes.straight_plan((3.0, 0.0))
+        plan[-1, 3:7] = scenes.quat_from_rpy(0, 0, yaw_plan)
+        o = oracle.tick(th, cloud, plan, ti)
+        i = int(np.nonzero((o.samples[:, 0] == 0.5) & (o.samples[:, 2] == 0.0))[0][0])
+        end_x = float(o.last_poses[i, 0])
+        dist = abs(plan[-1, 0] - end_x)
+        # yaw difference folded by fmod(yaw + 3.1416, 3.1416): +0.3 -> 0.3, -0.3 -> 3.1416 - 0.3
+        fold = math.fmod(yaw_plan + 3.1416, 3.1416)
+        assert o.costs[i] == pytest.approx(dist + fold, abs=1e-6)
+    # fewer than 2 poses -> -4: not reachable with these limits; guard on empty plan covered above
+
+
+def test_shortest_angle_and_twirling_tables():
+    cloud = np.zeros((0, 4), dtype=np.float32)
+    plan = scenes.straight_plan((3.0, 0.0))
+    th = configs.rotate_inplace_shipped("r", critics=[configs.critic(K.CRITIC_SHORTEST_ANGLE, weight=1.5)])
+    for dev, expect in ((0.7, [1.5, 3.0]), (0.0, [1.5, 3.0]), (-0.7, [3.0, 1.5])):
+        o = oracle.tick(th, cloud, plan, scenes.tick_input(heading_deviation=dev))
+        assert list(o.costs) == expect            # samples are (+w, -w)
+    th = configs.rotate_inplace_shipped("r", critics=[configs.critic(K.CRITIC_TWIRLING, weight=2.0)])
+    o = oracle.tick(th, cloud, plan, scenes.tick_input())
+    assert list(o.costs) == [1.0, 1.0]
+
+
+def test_stack_order_first_negative_wins():
+    # collision first: a colliding trajectory reports -1 even with a short plan (+10 critics)
+    th = configs.dd_simple_shipped(sim_time=2.0)
+    o = oracle.tick(th, wall_cloud(1.0), scenes.straight_plan((3.0, 0.0))[:2], ident_tick())
+    assert set(np.unique(o.costs)).issubset({-1.0} | set(o.costs[o.costs > 0]))
+    assert (o.costs == -1.0).any()
+    ok = o.costs[o.costs >= 0]
+    assert np.all(ok >= 20.0)          # stick_path 10 + toward_global_plan 10 + pure pursuit >= 0
+
+
+# ---- F3: tie-break -----------------------------------------------------------
+def test_tie_break_last_minimum_wins():
+    cloud = np.zeros((0, 4), dtype=np.float32)
+    plan = scenes.straight_plan((3.0, 0.0))
+    th = configs.rotate_inplace_shipped("r", critics=[configs.critic(K.CRITIC_TWIRLING, weight=1.0)])
+    o = oracle.tick(th, cloud, plan, scenes.tick_input())
+    assert list(o.costs) == [0.5, 0.5]
+    assert o.result.best_index == 1 and o.result.wz == -0.5      # `<=` keeps the last one
+    # all rejected -> ALL_TRAJECTORIES_FAIL, zero command, cost -1
+    th = configs.rotate_inplace_shipped("r")
+    blocked = np.array([[0.2, 0.0, 0.3, 0]] * 5, dtype=np.float32)
+    o = oracle.tick(th, blocked, plan, scenes.tick_input())
+    r = o.result
+    assert r.planner_state == K.ALL_TRAJECTORIES_FAIL and r.best_index == -1 and r.best_cost == -1.0
+    assert (r.vx, r.vy, r.wz) == (0.0, 0.0, 0.0)
+
+
+# ---- F4: SE(3) pose on a ramp ------------------------------------------------
+def test_ramp_pose_compose():
+    pitch = math.radians(-15.0)        # nose up
+    q = scenes.quat_from_rpy(0.1, pitch, 0.4)
+    ti = scenes.tick_input(pose=(1.0, 2.0, 0.5) + q)
+    th = configs.dd_simple_shipped()
+    poses, cub, _ = oracle.generate(th, ti, (0.5, 0.0, 0.2))
+    # independent numpy restatement of T_robot * [Rz(theta), (x, y, 0)]
+    x, y, z, w = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    n = len(poses)
+    dt = 2.0 / n
+    px = py = pth = np.float32(0)
+    for s in range(n):
+        nx = np.float32(float(px) + float(np.float32(0.5) * np.float32(math.cos(float(pth)))) * dt)
+        ny = np.float32(float(py) + float(np.float32(0.5) * np.float32(math.sin(float(pth)))) * dt)
+        pth = np.float32(float(pth) + float(np.float32(0.2)) * dt)
+        px, py = nx, ny
+        t = R @ np.array([float(px), float(py), 0.0]) + np.array([1.0, 2.0, 0.5])
+        np.testing.assert_allclose(poses[s, :3], t, atol=2e-6)
+    Rz = np.array([[math.cos(float(pth)), -math.sin(float(pth)), 0], [math.sin(float(pth)), math.cos(float(pth)), 0], [0, 0, 1]])
+    v = np.array(configs.cuboid_vertices())
+    world = (R @ Rz @ v.T).T + t
+    np.testing.assert_allclose(cub[-1], world, atol=1e-5)
+    assert poses[-1, 2] > 0.5 + 0.1        # climbing
+
+
+# ---- golden vectors ----------------------------------------------------------
+GOLDEN_SCENES = {
+    "F1_playground_L_st5": lambda: scenes.playground_scene((3.0, 1.0), 5.0),
+    "F1_playground_L_st2": lambda: scenes.playground_scene((3.0, 1.0), 2.0),
+    "F1_playground_R_st5": lambda: scenes.playground_scene((3.0, -1.0), 5.0),
+    "F1_playground_R_st2": lambda: scenes.playground_scene((3.0, -1.0), 2.0),
+    "F6_C1": lambda: scenes.bench_scene("C1"),
+    "F7_C2": lambda: scenes.bench_scene("C2"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN_SCENES))
+def test_oracle_reproduces_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sc = GOLDEN_SCENES[name]()
+    o = oracle.tick(sc.theory, sc.cloud, sc.plan, sc.tick, n_threads=4)
+    np.testing.assert_array_equal(o.steps, g["steps"])
+    np.testing.assert_array_equal(o.samples, g["samples"])
+    np.testing.assert_array_equal(o.costs, g["costs"])
+    r = o.result
+    assert [r.planner_state, r.best_index, r.n_samples, r.n_generated] == list(g["summary"])
+    assert [r.best_cost, r.vx, r.vy, r.wz] == list(g["best"])
+    assert [r.k_sum, r.steps_eval, r.steps_total] == list(g["counters"])
+
+
+def test_golden_c3_subrange():
+    """C3 (16384 x 80, 500k points) is too slow to re-run whole on the CPU suite:
+    re-score a slice and compare with the frozen vector."""
+    g = np.load(os.path.join(GOLD, "F8_C3.npz"))
+    sc = scenes.bench_scene("C3")
+    b, e = 9900, 10156
+    o = oracle.tick(sc.theory, sc.cloud, sc.plan, sc.tick, begin=b, end=e, n_threads=4)
+    np.testing.assert_array_equal(o.costs, g["costs"][b:e])
+    np.testing.assert_array_equal(o.steps, g["steps"][b:e])
+    assert int(g["summary"][1]) == 9999 and o.result.best_index == 9999
+
+
+def test_feed_oracle_voxel_centroids():
+    # two points in one 0.1 m voxel -> centroid; points outside the crop dropped
+    scan = np.array([[1.01, 0.01, 0.51], [1.03, 0.03, 0.53], [1.25, 0.0, 0.5],
+                     [30.0, 0.0, 0.5], [1.0, 0.0, -3.0], [np.nan, 0, 0]], dtype=np.float32)
+    out = oracle.feed(scan, (0, 0, 0.5, 0, 0, 0, 1), (10, 0, 0, 0, 0, 0, 1), 10.0, 2.0)
+    assert out.shape == (2, 3)
+    out = out[np.argsort(out[:, 0])]
+    np.testing.assert_allclose(out[0], [11.02, 0.02, 1.02], atol=1e-6)
+    np.testing.assert_allclose(out[1], [11.25, 0.0, 1.0], atol=1e-6)

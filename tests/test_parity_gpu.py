@@ -1,0 +1,337 @@
+"""GPU parity tests: the HIP path, called through the C-ABI, against the CPU
+oracle on the same seeded inputs and against the committed golden vectors.
+
+Bar (BASELINE.json north_star): identical step counts, samples and reject codes;
+per-trajectory cost and chosen cmd_vel within 1e-4; same best index.  A
+collision verdict may only differ where the oracle's own diagnostic says a cloud
+point lies within 1e-4 m of a cuboid face / the 1 m ball ("fragile",
+SURVEY.md 8d) -- the boolean box test is discontinuous there.
+"""
+import ctypes as C
+import math
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from dddmr_navigation_amd import _capi as K, configs, scenes, sharding
+from dddmr_navigation_amd.local_planner import LocalPlanner, RolloutError, Trajectory, PlannerState
+import oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-4
+
+
+def gpu_tick(theory, cloud, plan, tick, **kw):
+    with LocalPlanner([theory], max_points=max(len(cloud), 16), **kw) as lp:
+        lp.set_cloud(cloud)
+        lp.setPlan(plan)
+        res = lp.tick(theory.name.decode(), tick)
+        costs, steps, smp = lp.debug()
+    return res, costs, steps, smp
+
+
+def check_arrays(costs, steps, smp, o_costs, o_steps, o_smp, min_margin):
+    np.testing.assert_array_equal(steps, o_steps)
+    np.testing.assert_array_equal(smp, o_smp)
+    fragile = np.abs(min_margin) < TOL if min_margin is not None else np.zeros(len(costs), bool)
+    neg = (costs < 0) | (o_costs < 0)
+    code_bad = neg & (costs != o_costs) & ~fragile
+    assert not code_bad.any(), f"reject codes differ at {np.nonzero(code_bad)[0][:8]}"
+    both = (costs >= 0) & (o_costs >= 0)
+    if both.any():
+        assert np.max(np.abs(costs[both] - o_costs[both])) <= TOL
+    return int((neg & (costs != o_costs)).sum())
+
+
+def check_cmd(res, planner_state, best_index, best_cost, vx, vy, wz):
+    assert res.planner_state == planner_state
+    assert res.best_index == best_index
+    assert abs(res.vx - vx) <= TOL and abs(res.vy - vy) <= TOL and abs(res.wz - wz) <= TOL
+    assert abs(res.best_cost - best_cost) <= TOL
+
+
+def against_oracle(theory, cloud, plan, tick, **kw):
+    res, costs, steps, smp = gpu_tick(theory, cloud, plan, tick, **kw)
+    o = oracle.tick(theory, cloud, plan, tick, n_threads=8, want_margin=True)
+    flips = check_arrays(costs, steps, smp, o.costs, o.steps, o.samples, o.min_margin)
+    if flips == 0:
+        r = o.result
+        check_cmd(res, r.planner_state, r.best_index, r.best_cost, r.vx, r.vy, r.wz)
+    return res, costs, o
+
+
+# ---- golden vectors (no oracle run needed: committed bytes) -------------------
+GOLDEN = {
+    "F1_playground_L_st5": lambda: scenes.playground_scene((3.0, 1.0), 5.0),
+    "F1_playground_L_st2": lambda: scenes.playground_scene((3.0, 1.0), 2.0),
+    "F1_playground_R_st5": lambda: scenes.playground_scene((3.0, -1.0), 5.0),
+    "F1_playground_R_st2": lambda: scenes.playground_scene((3.0, -1.0), 2.0),
+    "F6_C1": lambda: scenes.bench_scene("C1"),
+    "F7_C2": lambda: scenes.bench_scene("C2"),
+    "F8_C3": lambda: scenes.bench_scene("C3"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(GOLDEN))
+def test_hip_matches_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    sc = GOLDEN[name]()
+    res, costs, steps, smp = gpu_tick(sc.theory, sc.cloud, sc.plan, sc.tick)
+    flips = check_arrays(costs, steps, smp, g["costs"], g["steps"], g["samples"], g["min_margin"])
+    assert flips <= 2
+    if flips == 0:
+        st, bi, n, _ = [int(v) for v in g["summary"]]
+        bc, vx, vy, wz = [float(v) for v in g["best"]]
+        assert res.n_samples == n
+        check_cmd(res, st, bi, bc, vx, vy, wz)
+
+
+# ---- shipped configurations, reference (variable-step) mode -------------------
+def test_shipped_dd_on_c1_cloud():
+    sc = scenes.bench_scene("C1")
+    th = configs.dd_simple_shipped()
+    res, costs, o = against_oracle(th, sc.cloud, sc.plan, scenes.tick_input(twist=(0.4, 0.0, 0.1)))
+    assert res.n_samples == 55 and (costs == -1.0).any() and (costs >= 0).any()
+
+
+def test_shipped_omni_with_twirling():
+    sc = scenes.bench_scene("C1")
+    th = configs.omni_simple_shipped()
+    res, costs, o = against_oracle(th, sc.cloud, sc.plan, scenes.tick_input(twist=(0.3, 0.1, 0.0)))
+    assert res.n_samples == o.result.n_samples > 200
+    assert (costs == K.COST_NOT_GENERATED).sum() == (o.costs == K.COST_NOT_GENERATED).sum()
+
+
+@pytest.mark.parametrize("dev", [0.8, -0.8, 0.0])
+def test_rotate_shortest_angle(dev):
+    sc = scenes.bench_scene("C1")
+    th = configs.rotate_inplace_shipped("differential_drive_rotate_shortest_angle", shortest=True)
+    res, costs, o = against_oracle(th, sc.cloud, sc.plan, scenes.tick_input(heading_deviation=dev))
+    assert res.n_samples == 2 and list(o.steps) == [126, 126]
+    assert res.wz == (0.5 if dev >= 0 else -0.5)
+
+
+def test_rotate_inplace_blocked_by_close_obstacle():
+    th = configs.rotate_inplace_shipped()
+    blocked = np.array([[0.3, 0.45, 0.3, 0]] * 6, dtype=np.float32)     # swept by a corner while turning
+    res, costs, o = against_oracle(th, blocked, scenes.s_curve_plan(), scenes.tick_input())
+    assert list(costs) == [-1.0, -1.0]
+    assert res.planner_state == K.ALL_TRAJECTORIES_FAIL and res.best_index == -1
+    assert (res.vx, res.vy, res.wz, res.best_cost) == (0.0, 0.0, 0.0, -1.0)
+
+
+def test_collision_min_max_critic():
+    sc = scenes.bench_scene("C1")
+    th = configs.dd_simple_shipped(critics=[configs.critic(K.CRITIC_COLLISION_MIN_MAX)] + configs.shipped_dd_critics()[1:])
+    against_oracle(th, sc.cloud, sc.plan, scenes.tick_input(twist=(0.4, 0.0, 0.0)))
+    both = configs.dd_simple_shipped(critics=[configs.critic(K.CRITIC_COLLISION), configs.critic(K.CRITIC_COLLISION_MIN_MAX),
+                                              configs.critic(K.CRITIC_TWIRLING)])
+    against_oracle(both, sc.cloud, sc.plan, scenes.tick_input(twist=(0.4, 0.0, 0.0)))
+
+
+def test_motor_constraint_list_mode_and_speed_zone():
+    sc = scenes.bench_scene("C1")
+    th = configs.dd_simple_shipped(use_motor_constraint=1, max_motor_shaft_rpm=55.0, gear_ratio=1.0)
+    res, costs, o = against_oracle(th, sc.cloud, sc.plan, scenes.tick_input(twist=(0.4, 0.0, 0.0)))
+    assert 0 < res.n_samples < 55
+    # perception speed zone caps the window (dd_simple...cpp:260-262) ...
+    res, _, o = against_oracle(configs.dd_simple_shipped(), sc.cloud, sc.plan,
+                               scenes.tick_input(twist=(0.4, 0, 0), allowed_max=0.3))
+    assert o.samples[:, 0].max() <= 0.3 + 1e-6
+    # ... even below what the robot can decelerate to (:273-276)
+    res, _, o = against_oracle(configs.dd_simple_shipped(), sc.cloud, sc.plan,
+                               scenes.tick_input(twist=(0.9, 0, 0), allowed_max=0.2))
+    assert np.allclose(np.unique(o.samples[:, 0]), 0.45)
+    # omni rejects instead (omni_simple...cpp:406-411)
+    res, costs, o = against_oracle(configs.omni_simple_shipped(), sc.cloud, sc.plan,
+                                   scenes.tick_input(twist=(0.3, 0.0, 0), allowed_max=0.25))
+    assert (costs == K.COST_NOT_GENERATED).any()
+
+
+# ---- edge cases -----------------------------------------------------------------
+def test_empty_and_tiny_clouds():
+    sc = scenes.playground_scene()
+    empty = np.zeros((0, 4), dtype=np.float32)
+    res, costs, o = against_oracle(sc.theory, empty, sc.plan, sc.tick)
+    assert (costs >= 0).all()
+    # 4 points inside the robot: "< 5 points -> critic returns 0" (collision_model.cpp:53-55)
+    four = np.array([[0.1, 0.0, 0.3, 0]] * 4, dtype=np.float32)
+    res, costs, o = against_oracle(sc.theory, four, sc.plan, sc.tick)
+    assert (costs >= 0).all()
+    five = np.array([[0.1, 0.0, 0.3, 0]] * 5, dtype=np.float32)
+    res, costs, o = against_oracle(sc.theory, five, sc.plan, sc.tick)
+    assert (costs == -1.0).all() and res.planner_state == K.ALL_TRAJECTORIES_FAIL
+
+
+def test_short_and_empty_prune_plan():
+    sc = scenes.playground_scene()
+    res, costs, o = against_oracle(sc.theory, sc.cloud, sc.plan[:2], sc.tick)   # < 3 poses: +10 critics
+    assert costs[costs >= 0].min() >= 20.0
+    res, costs, o = against_oracle(sc.theory, sc.cloud, sc.plan[:0], sc.tick)   # empty: pure pursuit -4
+    assert set(np.unique(costs)) <= {-1.0, -4.0}
+    assert res.planner_state == K.ALL_TRAJECTORIES_FAIL
+
+
+def test_ramp_pose_and_offset_world():
+    sc = scenes.bench_scene("C1")
+    q = scenes.quat_from_rpy(0.05, math.radians(-10.0), 0.3)
+    c, s = math.cos(0.3), math.sin(0.3)
+    cloud = sc.cloud.copy()
+    xy = cloud[:, :2].copy()
+    cloud[:, 0] = 50.0 + c * xy[:, 0] - s * xy[:, 1]
+    cloud[:, 1] = -20.0 + s * xy[:, 0] + c * xy[:, 1]
+    cloud[:, 2] += 1.0
+    plan = sc.plan.copy()
+    pxy = plan[:, :2].copy()
+    plan[:, 0] = 50.0 + c * pxy[:, 0] - s * pxy[:, 1]
+    plan[:, 1] = -20.0 + s * pxy[:, 0] + c * pxy[:, 1]
+    plan[:, 2] = 1.0
+    tick = scenes.tick_input(pose=(50.0, -20.0, 1.0) + q, twist=(0.5, 0.0, 0.0))
+    res, costs, o = against_oracle(configs.dd_simple_shipped(), cloud, plan, tick)
+    assert (costs == -1.0).any() and (costs >= 0).any()
+
+
+@pytest.mark.parametrize("width", [3, 4, 8])
+def test_cloud_strides(width):
+    sc = scenes.bench_scene("C1")
+    wide = np.zeros((len(sc.cloud), width), dtype=np.float32)
+    wide[:, :3] = sc.cloud[:, :3]
+    if width > 4:
+        wide[:, 4:] = 777.0           # PCL padding must be ignored
+    g = np.load(os.path.join(GOLD, "F6_C1.npz"))
+    res, costs, steps, smp = gpu_tick(sc.theory, wide, sc.plan, sc.tick)
+    check_arrays(costs, steps, smp, g["costs"], g["steps"], g["samples"], g["min_margin"])
+
+
+def test_error_codes():
+    sc = scenes.bench_scene("C1")
+    with LocalPlanner([sc.theory], max_points=100, max_steps=10, max_plan_poses=8) as lp:
+        with pytest.raises(RolloutError) as e:
+            lp.set_cloud(sc.cloud)
+        assert e.value.code == K.ERR_CAPACITY
+        with pytest.raises(RolloutError) as e:
+            lp.setPlan(sc.plan)
+        assert e.value.code == K.ERR_CAPACITY
+        lp.setPlan(sc.plan[:8])
+        with pytest.raises(RolloutError) as e:
+            lp.tick("no_such_theory", sc.tick)
+        assert e.value.code == K.ERR_UNKNOWN_THEORY
+        with pytest.raises(RolloutError) as e:
+            lp.tick(sc.theory.name.decode(), sc.tick)          # 20 steps > max_steps 10
+        assert e.value.code == K.ERR_CAPACITY
+    with pytest.raises(RolloutError):
+        LocalPlanner([sc.theory], device=99)
+
+
+def test_host_mirror_compute_velocity_command_and_poses():
+    sc = scenes.playground_scene()
+    with LocalPlanner(configs.shipped_theories() + [sc.theory.__class__.from_buffer_copy(sc.theory)]) as lp:
+        pass
+    with LocalPlanner([sc.theory]) as lp:
+        lp.set_cloud(sc.cloud)
+        lp.setPlan(sc.plan)
+        best = Trajectory()
+        assert (best.xv_, best.cost_) == (0.0, -1.0)
+        st = lp.computeVelocityCommand("differential_drive_simple", best, sc.tick)
+        assert st == PlannerState.TRAJECTORY_FOUND
+        o = oracle.tick(sc.theory, sc.cloud, sc.plan, sc.tick)
+        assert best.index == o.result.best_index
+        assert abs(best.xv_ - o.result.vx) <= TOL and abs(best.thetav_ - o.result.wz) <= TOL
+        poses = lp.best_poses()
+        ref, _, _ = oracle.generate(sc.theory, sc.tick, o.samples[best.index])
+        assert poses.shape == ref.shape
+        np.testing.assert_allclose(poses, ref, atol=1e-5)
+
+
+# ---- sharding on one GPU: every rank's context, then the 8-byte min -----------
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_contexts_agree_with_unsharded(world):
+    sc = scenes.bench_scene("C2")
+    name = sc.theory.name.decode()
+    res0, costs0, _, _ = gpu_tick(sc.theory, sc.cloud, sc.plan, sc.tick)
+    keys, parts, ctxs = [], [], []
+    for r in range(world):
+        lp = LocalPlanner([sc.theory], max_points=len(sc.cloud), rank=r, world_size=world)
+        lp.set_cloud(sc.cloud)
+        lp.setPlan(sc.plan)
+        res = lp.tick(name, sc.tick)
+        b, e = sharding.shard_range(r, world, res.n_samples)
+        assert (res.local_begin, res.n_local) == (b, e - b)
+        keys.append(res.key)
+        parts.append(lp.debug()[0])
+        ctxs.append(lp)
+    np.testing.assert_array_equal(np.concatenate(parts), costs0)       # shards tile the batch exactly
+    red = min(keys)
+    assert red == res0.key
+    for lp in ctxs:
+        out = lp.resolve(red)
+        assert out.best_index == res0.best_index
+        assert (out.vx, out.vy, out.wz) == (res0.vx, res0.vy, res0.wz)
+        assert abs(out.best_cost - res0.best_cost) <= 1e-6
+        lp.close()
+
+
+# ---- size-independent properties at full size (C3: 16384 x 80 vs 500k points) --
+def test_full_size_properties_c3():
+    sc = scenes.bench_scene("C3")
+    name = sc.theory.name.decode()
+    with LocalPlanner([sc.theory], max_points=len(sc.cloud) + 1000) as lp:
+        lp.set_cloud(sc.cloud)
+        lp.setPlan(sc.plan)
+        r1 = lp.tick(name, sc.tick)
+        c1 = lp.debug()[0].copy()
+        r2 = lp.tick(name, sc.tick)                                  # idempotence
+        np.testing.assert_array_equal(lp.debug()[0], c1)
+        assert (r1.key, r1.best_index) == (r2.key, r2.best_index)
+        # the verdicts do not depend on the order of the cloud ...
+        perm = np.random.default_rng(1).permutation(len(sc.cloud))
+        lp.set_cloud(sc.cloud[perm])
+        r3 = lp.tick(name, sc.tick)
+        np.testing.assert_array_equal(lp.debug()[0], c1)
+        # ... nor on points no trajectory can reach (other floors, far away)
+        extra = np.array([[0.5, 0.0, 3.2, 0.0]] * 500 + [[40.0, 40.0, 0.3, 0.0]] * 500, dtype=np.float32)
+        lp.set_cloud(np.concatenate([sc.cloud, extra]))
+        r4 = lp.tick(name, sc.tick)
+        np.testing.assert_array_equal(lp.debug()[0], c1)
+        assert r4.key == r1.key
+    # argmin == the reference's scan over the per-trajectory costs
+    best, m = -1, 9999999
+    for i, c in enumerate(c1):
+        if c >= 0 and c <= m:
+            best, m = i, c
+    assert r1.best_index == best and r1.best_cost == c1[best]
+    assert 0.05 < (c1 == -1.0).mean() < 0.98
+
+
+def test_set_cloud_from_sensor_thread_while_ticking():
+    sc = scenes.bench_scene("C1")
+    name = sc.theory.name.decode()
+    blocked = np.array([[0.1, 0.0, 0.3, 0]] * 8, dtype=np.float32)
+    with LocalPlanner([sc.theory]) as lp:
+        lp.set_cloud(sc.cloud)
+        lp.setPlan(sc.plan)
+        free_key = lp.tick(name, sc.tick).key
+        stop = threading.Event()
+        errors = []
+
+        def sensor():
+            i = 0
+            while not stop.is_set():
+                try:
+                    lp.set_cloud(sc.cloud if i % 2 == 0 else blocked)
+                except Exception as ex:      # pragma: no cover
+                    errors.append(ex)
+                i += 1
+
+        t = threading.Thread(target=sensor)
+        t.start()
+        seen = set()
+        for _ in range(300):
+            seen.add(lp.tick(name, sc.tick).key)
+        stop.set()
+        t.join()
+        assert not errors
+        assert seen <= {free_key, K.KEY_NONE}          # never a torn cloud
