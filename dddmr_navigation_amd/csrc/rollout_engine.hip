@@ -30,6 +30,7 @@ namespace {
 
 constexpr uint32_t kCapCells = 1u << 20;
 constexpr int kMaxAxis = 4096;
+constexpr int kScoreLdsMax = 96 * 1024;   // dynamic LDS one k_score workgroup may use
 
 struct Window {              // result of a theory's initialise()
   std::vector<float> ax, ay, ath;
@@ -365,7 +366,8 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
       HIPCHK(ctx, hipEventCreateWithFlags(&ctx->cloud_ready[i], hipEventDisableTiming));
     }
     HIPCHK(ctx, hipMalloc(&ctx->pt_slot, P * sizeof(uint2)));
-    HIPCHK(ctx, hipMalloc(&ctx->sorted, P * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&ctx->sorted, (P + kItem) * sizeof(float4)));
+    HIPCHK(ctx, hipMemset(ctx->sorted, 0, (P + kItem) * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&ctx->cell_count, (kCapCells + 1) * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->cell_start, (kCapCells + 1) * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(ctx->cell_count, 0, (kCapCells + 1) * sizeof(uint32_t)));
@@ -386,6 +388,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipHostMalloc(&ctx->result_host, sizeof(DevResult), hipHostMallocDefault));
     const int rc = perception_alloc(ctx->feed, P);
     if (rc != 0) return fail(ctx, DDDMR_ERR_HIP, "perception scratch allocation failed");
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
     HIPCHK(ctx, hipDeviceSynchronize());
     return DDDMR_OK;
   };
@@ -617,9 +620,10 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   // trajectories per workgroup: ~one (trajectory, step) pair per lane
   int tile = ctx->tile_override > 0 ? ctx->tile_override : kScoreThreads / s_tick;
   tile = std::min(std::max(tile, 1), kMaxTile);
-  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m) > 60 * 1024) --tile;
-  const size_t lds = score_lds_bytes(tile, s_tick, k.m);
-  if (lds > 64 * 1024) return fail(ctx, DDDMR_ERR_CAPACITY, "horizon needs %zu bytes of LDS", lds);
+  const bool is_omni = th->kind == DDDMR_THEORY_OMNI_SIMPLE;
+  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0) > 72 * 1024) --tile;
+  const size_t lds = score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0);
+  if (lds > (size_t)kScoreLdsMax) return fail(ctx, DDDMR_ERR_CAPACITY, "horizon needs %zu bytes of LDS", lds);
   k.tile = tile;
 
   // ---- cloud front buffer + local costmap tile ----
@@ -641,13 +645,22 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   } unbusy{ctx};
   k.n_points = (int)ctx->cloud_n[cidx];
   tile_extent(*th, w, k.R, k.t, sim_time_eff, k.rmin, k.rmax);
-  float cell = ctx->cell_size;
+  // A cuboid's AABB (clipped to the 2 m wide search ball) must not span more than
+  // kRows cell rows: rows <= span / cell + 2.
+  double diam = 0;
+  for (int a = 0; a < 8; ++a)
+    for (int b = a + 1; b < 8; ++b) {
+      const double dx = th->cuboid[a][0] - th->cuboid[b][0], dy = th->cuboid[a][1] - th->cuboid[b][1],
+                   dz = th->cuboid[a][2] - th->cuboid[b][2];
+      diam = std::max(diam, std::sqrt(dx * dx + dy * dy + dz * dz));
+    }
+  float cell = std::max(ctx->cell_size, (float)(std::min(diam, 2.0) * 1.001 / (kRows - 2)));
   for (;;) {
     k.gnx = std::max(1, (int)std::ceil((k.rmax[0] - k.rmin[0]) / cell));
     k.gny = std::max(1, (int)std::ceil((k.rmax[1] - k.rmin[1]) / cell));
     k.gnz = std::max(1, (int)std::ceil((k.rmax[2] - k.rmin[2]) / cell));
     const uint64_t nc = (uint64_t)k.gnx * k.gny * k.gnz;
-    if (nc <= kCapCells) { k.n_cells = (int)nc; break; }
+    if (nc <= kCapCells && k.gnx < 32000 && k.gny < 32000) { k.n_cells = (int)nc; break; }
     cell *= 1.5f;
   }
   k.inv_cell = 1.0f / cell;
@@ -701,7 +714,8 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   ctx->last = k;
   ctx->have_last = true;
   if (r.overflow)
-    return fail(ctx, DDDMR_ERR_CAPACITY, "a trajectory needed more than %d steps", s_tick);
+    return fail(ctx, DDDMR_ERR_CAPACITY, "device capacity flag %u (1: trajectory longer than %d steps, 2: cuboid spans more than %d cell rows)",
+                r.overflow, s_tick, kRows);
   out->device_ms = ms;
   out->score_ms = score_ms;
   out->n_points_binned = r.n_binned;

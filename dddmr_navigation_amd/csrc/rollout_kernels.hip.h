@@ -18,12 +18,16 @@
 // build of the reference.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <limits.h>
 #include <stdint.h>
 
 #include "../../include/dddmr_rollout.h"
 
 namespace dddmr {
 
+#ifndef DDDMR_SCORE_WPE
+#define DDDMR_SCORE_WPE 2   // min waves per SIMD the register allocator must allow for k_score
+#endif
 constexpr int kScoreThreads = 256;
 constexpr int kMaxTile = 16;          // trajectories per workgroup (upper bound)
 constexpr int kMaxPlan = 512;         // prune-plan poses kept in LDS
@@ -211,6 +215,19 @@ __global__ __launch_bounds__(256) void k_bin_scatter(DevTick k, const float4* __
 
 // ---------------------------------------------------------------------------
 // fused rollout + critics + argmin
+//
+// One workgroup scores a tile of `tile` consecutive trajectories (~256
+// (trajectory, step) pairs).  Phases:
+//   A  theta recurrence (one lane per trajectory; 2 dependent ops per step)
+//   B  double sin/cos of every theta_k, all lanes
+//   C  x,y recurrence (one lane per trajectory)
+//   D1 one lane per pair: pose, path critics, cuboid -> OBB record in LDS,
+//      candidate cell range
+//   D2 one lane per (pair, cell row): the row's contiguous run of cell-sorted
+//      points; workgroup exclusive scan of the 8-point work items
+//   D3 load-balanced walk: every lane takes an equal share of the flattened
+//      item list; trajectory-level early exit through LDS flags
+//   E  stacked scoring + packed-key wave min-reduction + one atomicMin
 // ---------------------------------------------------------------------------
 struct TrajHead {     // per-trajectory header in LDS
   float vx, vy, w;
@@ -224,23 +241,40 @@ struct TrajHead {     // per-trajectory header in LDS
   double pp_yaw;      // PurePursuitModel: folded yaw of the pose difference
 };
 
-// dynamic LDS carve (all rows are max_steps+1 long):
-//   TrajHead head[tile]; float4 plan[m]; double2 sc[tile][S1]; float th[tile][S1];
-//   float2 xy[tile][S1]; float dist[tile][S1];
-__host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m) {
+constexpr int kRecWords = 21;       // odd stride: conflict-free field reads across lanes
+constexpr int kRecWordsMM = 27;     // + world AABB for CollisionMinMaxModel
+constexpr int kRows = 8;            // y-rows of cells one cuboid AABB may span (host sizes the cells for it)
+constexpr int kItem = 8;            // points per work item of the collision walk
+
+// dynamic LDS carve, see k_score (rows are max_steps+1 long):
+__host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m, bool omni, bool want_mm) {
   const size_t S1 = (size_t)max_steps + 1;
+  const size_t Q = (size_t)tile * (size_t)max_steps;
   size_t b = 0;
   b += sizeof(TrajHead) * (size_t)tile;
   b = (b + 15) & ~(size_t)15;
-  b += 16 * (size_t)(m > 0 ? m : 1);
-  b += 16 * (size_t)tile * S1;   // sc
-  b += 4 * (size_t)tile * S1;    // th
-  b += 8 * (size_t)tile * S1;    // xy
-  b += 4 * (size_t)tile * S1;    // dist
+  b += 16 * (size_t)(m > 0 ? m : 1);                 // plan
+  b += 16 * (size_t)tile * S1 * (omni ? 2 : 1);      // sc (+ sc2 for omni)
+  b += 4 * (size_t)tile * S1;                        // th
+  b += 8 * (size_t)tile * S1;                        // xy
+  b += 4 * (size_t)tile * S1;                        // dist
+  b += 4 * (size_t)(want_mm ? kRecWordsMM : kRecWords) * Q;   // OBB records
+  b += 4 * (Q * kRows + 1);                          // item prefix sums per (pair,row) slot
+  b += 8 * (Q * kRows);                              // segment start + length per slot
+  b += 64;                                           // scan scratch
   return (b + 15) & ~(size_t)15;
 }
 
-__global__ __launch_bounds__(kScoreThreads) void k_score(
+__device__ __forceinline__ bool box_test(const float* r, float x, float y, float z) {
+  // collision_model.cpp:124-139, float arithmetic in source order
+  const float dx = fsub(x, r[0]), dy = fsub(y, r[1]), dz = fsub(z, r[2]);
+  const float xv = fabsf(dot3(dx, dy, dz, r[3], r[4], r[5]));
+  const float yv = fabsf(dot3(dx, dy, dz, r[6], r[7], r[8]));
+  const float zv = fabsf(dot3(dx, dy, dz, r[9], r[10], r[11]));
+  return xv <= r[12] && yv <= r[13] && zv <= r[14];
+}
+
+__global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     DevTick k, const float* __restrict__ axes, const float4* __restrict__ samples,
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
     const float4* __restrict__ sorted, double* __restrict__ costs, int32_t* __restrict__ steps_out,
@@ -248,6 +282,10 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tile = k.tile;
   const int S1 = k.max_steps + 1;
+  const int Qcap = tile * k.max_steps;
+  const bool omni = (k.kind == DDDMR_THEORY_OMNI_SIMPLE);
+  const bool need_box = k.want_collision != 0, need_mm = k.want_minmax != 0;
+  const int rec_words = need_mm ? kRecWordsMM : kRecWords;
   size_t ofs = 0;
   TrajHead* head = reinterpret_cast<TrajHead*>(lds_raw);
   ofs += sizeof(TrajHead) * (size_t)tile;
@@ -256,22 +294,42 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(
   ofs += 16 * (size_t)(k.m > 0 ? k.m : 1);
   double2* sc = reinterpret_cast<double2*>(lds_raw + ofs);
   ofs += 16 * (size_t)tile * S1;
+  double2* sc2 = sc;
+  if (omni) {
+    sc2 = reinterpret_cast<double2*>(lds_raw + ofs);
+    ofs += 16 * (size_t)tile * S1;
+  }
   float* th = reinterpret_cast<float*>(lds_raw + ofs);
   ofs += 4 * (size_t)tile * S1;
   float2* xy = reinterpret_cast<float2*>(lds_raw + ofs);
   ofs += 8 * (size_t)tile * S1;
   float* dist = reinterpret_cast<float*>(lds_raw + ofs);
+  ofs += 4 * (size_t)tile * S1;
+  float* rec = reinterpret_cast<float*>(lds_raw + ofs);
+  ofs += 4 * (size_t)rec_words * Qcap;
+  uint32_t* pref = reinterpret_cast<uint32_t*>(lds_raw + ofs);
+  ofs += 4 * ((size_t)Qcap * kRows + 1);
+  uint32_t* seg_p = reinterpret_cast<uint32_t*>(lds_raw + ofs);
+  ofs += 4 * (size_t)Qcap * kRows;
+  uint32_t* seg_len = reinterpret_cast<uint32_t*>(lds_raw + ofs);
+  ofs += 4 * (size_t)Qcap * kRows;
+  uint32_t* wsum = reinterpret_cast<uint32_t*>(lds_raw + ofs);
 
   const int tid = threadIdx.x;
-  const int t0 = blockIdx.x * tile;                 // first local trajectory of this tile
-  const int nt = min(tile, k.n_local - t0);         // trajectories in this tile
+  const int lane = tid & 63, wid = tid >> 6;
+  // Tile b scores local trajectories b, b + n_tiles, b + 2 n_tiles, ...: neighbours
+  // in sample order head the same way and would make whole tiles cheap (open
+  // space) or expensive (along a wall); striding mixes them so that the
+  // workgroups carry similar amounts of collision work.
+  const int n_tiles = gridDim.x;
+  const int nt = (k.n_local - (int)blockIdx.x + n_tiles - 1) / n_tiles;   // <= tile
 
   // ---- stage the prune plan (float xyz, model_shared_data.h:83-91) ----
   for (int i = tid; i < k.m; i += kScoreThreads) plan[i] = plan_xyz[i];
 
   // ---- phase A: sample, generation gates, step count, theta recurrence ----
   if (tid < nt) {
-    const int li = t0 + tid;
+    const int li = (int)blockIdx.x + tid * n_tiles;
     const int gi = k.begin + li;
     float vx, vy, w;
     if (k.list_mode) {
@@ -295,7 +353,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(
       if ((k.min_vel_x >= 0 && vmag + eps < k.min_vel_x) &&
           (k.min_vel_theta >= 0 && fabs((double)w) + eps < k.min_vel_theta)) ok = false;
       if (k.max_vel_x >= 0 && vmag - eps > k.max_vel_x) ok = false;
-    } else if (k.kind == DDDMR_THEORY_OMNI_SIMPLE) {
+    } else if (omni) {
       // omni_simple_trajectory_generator_theory.cpp:387-411
       vmag = hypot((double)vx, (double)vy);
       if ((k.min_vel_trans >= 0 && vmag + eps < k.min_vel_trans) &&
@@ -351,15 +409,21 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(
     }
   }
 
-  // ---- phase B: double sin/cos of every theta_k (k = 0..steps) ----
-  // theta_k feeds both the next position update (cos/sin of the float state) and
-  // the pose's AngleAxisd(theta) rotation (dd_simple...cpp:416).
+  // ---- phase B: double sin/cos of every theta_k (k = 0..steps), all lanes ----
+  // theta_k feeds the next position update (cos/sin of the float state) and the
+  // pose's AngleAxisd(theta) rotation (dd_simple...cpp:416); the omni theory also
+  // needs cos/sin(M_PI_2 + theta) in double (omni_simple...cpp:501-502).
   for (int idx = tid; idx < nt * S1; idx += kScoreThreads) {
     const int j = idx / S1, s = idx - j * S1;
     if (s <= head[j].steps) {
+      const double a = (double)th[(size_t)j * S1 + s];
       double sn, cs;
-      sincos((double)th[(size_t)j * S1 + s], &sn, &cs);
+      sincos(a, &sn, &cs);
       sc[(size_t)j * S1 + s] = make_double2(cs, sn);
+      if (omni) {
+        sincos(M_PI_2 + a, &sn, &cs);
+        sc2[(size_t)j * S1 + s] = make_double2(cs, sn);
+      }
     }
   }
   __syncthreads();
@@ -368,22 +432,17 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(
   if (tid < nt) {
     const TrajHead h = head[tid];
     const double2* scr = sc + (size_t)tid * S1;
+    const double2* scr2 = sc2 + (size_t)tid * S1;
     float2* xr = xy + (size_t)tid * S1;
     float px = 0.f, py = 0.f;
-    const bool omni = (k.kind == DDDMR_THEORY_OMNI_SIMPLE);
     for (int s = 0; s < h.steps; ++s) {
       const double2 cs = scr[s];
       const float cf = (float)cs.x, sf = (float)cs.y;  // cos/sin(float) overloads
-      double ix, iy;
+      double ix = (double)fmul(h.vx, cf), iy = (double)fmul(h.vx, sf);
       if (omni) {
-        // cos(M_PI_2 + theta), sin(M_PI_2 + theta) in double (omni...cpp:501-502)
-        double s2, c2;
-        sincos(M_PI_2 + (double)th[(size_t)tid * S1 + s], &s2, &c2);
-        ix = (double)fmul(h.vx, cf) + (double)h.vy * c2;
-        iy = (double)fmul(h.vx, sf) + (double)h.vy * s2;
-      } else {
-        ix = (double)fmul(h.vx, cf);
-        iy = (double)fmul(h.vx, sf);
+        const double2 c2 = scr2[s];
+        ix += (double)h.vy * c2.x;
+        iy += (double)h.vy * c2.y;
       }
       px = (float)((double)px + ix * h.dt);
       py = (float)((double)py + iy * h.dt);
@@ -392,10 +451,11 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(
   }
   __syncthreads();
 
-  // ---- phase D: one (trajectory, step) pair per lane ----
+  // ---- phase D1: one (trajectory, step) pair per lane ----
   int total_pairs = 0;
   if (nt > 0) total_pairs = head[nt - 1].pair_base + head[nt - 1].steps;
   const bool cloud_ok = k.n_points >= 5;   // collision_model.cpp:53-55
+  const bool do_coll = cloud_ok && (need_box || need_mm);
   for (int q = tid; q < total_pairs; q += kScoreThreads) {
     int j = 0;
     while (j + 1 < nt && head[j + 1].pair_base <= q) ++j;
@@ -437,47 +497,44 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(
       const double D20 = L[2] * k.planR[0] + L[5] * k.planR[3] + L[8] * k.planR[6];
       double yaw = 0.0;
       if (fabs(D20) < 1.0) yaw = atan2(D10, D00);   // getEulerYPR, solution 1
-      const double yf = fmod(yaw + 3.1416, 3.1416);
       // weights are applied in phase E (they are per-critic)
       head[j].pp_dist = sqrt(tx * tx + ty * ty + tz * tz);
-      head[j].pp_yaw = yf;
+      head[j].pp_yaw = fmod(yaw + 3.1416, 3.1416);
     }
 
-    // ---- collision critics ----
-    if (cloud_ok && (k.want_collision | k.want_minmax)) {
-      // pcl::transformPointCloud(cuboid, Affine3d): double multiply-add, cast to float
-      float vxs[8], vys[8], vzs[8];
+    // ---- cuboid -> OBB record (collision_model.cpp:85-115) ----
+    if (do_coll) {
+      // pcl::transformPointCloud(cuboid, Affine3d): double multiply-add, cast to float.
+      // Vertex order blb,brb,blt,flb,...: keep [0..3] for the axes, fold the rest.
+      float v[4][3];
       float mnx = 3.402823466e+38f, mny = mnx, mnz = mnx, mxx = -mnx, mxy = -mnx, mxz = -mnx;
-#pragma unroll
-      for (int v = 0; v < 8; ++v) {
-        const double cx = k.cub[3 * v + 0], cy = k.cub[3 * v + 1], cz = k.cub[3 * v + 2];
-        vxs[v] = (float)(L[0] * cx + L[1] * cy + L[2] * cz + T[0]);
-        vys[v] = (float)(L[3] * cx + L[4] * cy + L[5] * cz + T[1]);
-        vzs[v] = (float)(L[6] * cx + L[7] * cy + L[8] * cz + T[2]);
-        mnx = fminf(mnx, vxs[v]); mxx = fmaxf(mxx, vxs[v]);
-        mny = fminf(mny, vys[v]); mxy = fmaxf(mxy, vys[v]);
-        mnz = fminf(mnz, vzs[v]); mxz = fmaxf(mxz, vzs[v]);
-      }
-      // collision_model.cpp:85-115: centre, axes, half extents (float / double mix)
       float ccx = 0.f, ccy = 0.f, ccz = 0.f;
 #pragma unroll
-      for (int v = 0; v < 8; ++v) {
-        ccx = fadd(ccx, vxs[v]); ccy = fadd(ccy, vys[v]); ccz = fadd(ccz, vzs[v]);
+      for (int vtx = 0; vtx < 8; ++vtx) {
+        const double cx = k.cub[3 * vtx + 0], cy = k.cub[3 * vtx + 1], cz = k.cub[3 * vtx + 2];
+        const float wx = (float)(L[0] * cx + L[1] * cy + L[2] * cz + T[0]);
+        const float wy = (float)(L[3] * cx + L[4] * cy + L[5] * cz + T[1]);
+        const float wz = (float)(L[6] * cx + L[7] * cy + L[8] * cz + T[2]);
+        if (vtx < 4) { v[vtx][0] = wx; v[vtx][1] = wy; v[vtx][2] = wz; }
+        mnx = fminf(mnx, wx); mxx = fmaxf(mxx, wx);
+        mny = fminf(mny, wy); mxy = fmaxf(mxy, wy);
+        mnz = fminf(mnz, wz); mxz = fmaxf(mxz, wz);
+        ccx = fadd(ccx, wx); ccy = fadd(ccy, wy); ccz = fadd(ccz, wz);
       }
-      ccx = ccx / 8.f; ccy = ccy / 8.f; ccz = ccz / 8.f;
-      float ax[3][3];
-      float half[3];
+      float* r = rec + (size_t)q * rec_words;
+      r[0] = ccx / 8.f; r[1] = ccy / 8.f; r[2] = ccz / 8.f;
       const int vi[3] = {3, 1, 2};
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        const float ex = fsub(vxs[vi[a]], vxs[0]), ey = fsub(vys[vi[a]], vys[0]), ez = fsub(vzs[vi[a]], vzs[0]);
+        const float ex = fsub(v[vi[a]][0], v[0][0]), ey = fsub(v[vi[a]][1], v[0][1]), ez = fsub(v[vi[a]][2], v[0][2]);
         const float len = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
         const double h = (double)len / 2.;
-        half[a] = (float)h;                    // len/2 is exact in float
-        ax[a][0] = (float)((double)ex / (2. * h));
-        ax[a][1] = (float)((double)ey / (2. * h));
-        ax[a][2] = (float)((double)ez / (2. * h));
+        r[12 + a] = (float)h;                    // len/2 is exact in float
+        r[3 + 3 * a + 0] = (float)((double)ex / (2. * h));
+        r[3 + 3 * a + 1] = (float)((double)ey / (2. * h));
+        r[3 + 3 * a + 2] = (float)((double)ez / (2. * h));
       }
+      r[15] = px; r[16] = py; r[17] = pz;
       // candidate cells: cuboid AABB clipped to the 1 m search ball's AABB
       const float lox = fmaxf(mnx, px - 1.0f), hix = fminf(mxx, px + 1.0f);
       const float loy = fmaxf(mny, py - 1.0f), hiy = fminf(mxy, py + 1.0f);
@@ -485,33 +542,109 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(
       int cy0 = (int)floorf((loy - k.gmin[1]) * k.inv_cell), cy1 = (int)floorf((hiy - k.gmin[1]) * k.inv_cell);
       cx0 = max(cx0, 0); cy0 = max(cy0, 0);
       cx1 = min(cx1, k.gnx - 1); cy1 = min(cy1, k.gny - 1);
-      bool hit_box = false, hit_mm = false;
-      const bool need_box = k.want_collision != 0, need_mm = k.want_minmax != 0;
-      if (cx0 <= cx1) {
-        for (int cy = cy0; cy <= cy1; ++cy) {
-          // z is the fastest cell axis, then x: one contiguous run per y-row
-          const uint32_t b = cell_start[(cy * k.gnx + cx0) * k.gnz];
-          const uint32_t e = cell_start[(cy * k.gnx + cx1 + 1) * k.gnz];
-          for (uint32_t i = b; i < e; ++i) {
-            const float4 p = sorted[i];
-            // radiusSearch(pose, 1.0): FLANN keeps dist^2 < r^2
-            if (!(l2_simple(px, py, pz, p.x, p.y, p.z) < 1.0f)) continue;
-            if (need_box) {
-              const float dx = fsub(p.x, ccx), dy = fsub(p.y, ccy), dz = fsub(p.z, ccz);
-              const float xv = fabsf(dot3(dx, dy, dz, ax[0][0], ax[0][1], ax[0][2]));
-              const float yv = fabsf(dot3(dx, dy, dz, ax[1][0], ax[1][1], ax[1][2]));
-              const float zv = fabsf(dot3(dx, dy, dz, ax[2][0], ax[2][1], ax[2][2]));
-              hit_box |= (xv <= half[0] && yv <= half[1] && zv <= half[2]);
-            }
-            if (need_mm) {
-              hit_mm |= (p.x >= mnx && p.x <= mxx && p.y >= mny && p.y <= mxy && p.z >= mnz && p.z <= mxz);
-            }
-          }
-          if ((hit_box || !need_box) && (hit_mm || !need_mm)) break;
-        }
+      if (cx0 > cx1 || cy0 > cy1) { cx0 = 1; cx1 = 0; cy0 = 1; cy1 = 0; }
+      reinterpret_cast<int*>(r)[18] = (cx0 & 0xFFFF) | (cx1 << 16);
+      reinterpret_cast<int*>(r)[19] = (cy0 & 0xFFFF) | (cy1 << 16);
+      reinterpret_cast<int*>(r)[20] = j;
+      if (need_mm) { r[21] = mnx; r[22] = mny; r[23] = mnz; r[24] = mxx; r[25] = mxy; r[26] = mxz; }
+      if (cy1 - cy0 + 1 > kRows) atomicOr(overflow, 2u);   // host sizes the cells so this cannot happen
+    }
+  }
+  __syncthreads();
+
+  if (do_coll && total_pairs > 0) {
+    // ---- phase D2: row segments per pair -----------------------------------
+    // z is the fastest cell axis, then x: the cells [cx0..cx1] x all z of one y-row
+    // are ONE contiguous run [start[(cy*gnx+cx0)*gnz], start[(cy*gnx+cx1+1)*gnz]).
+    // Slot q*kRows + r holds row r of pair q.  Work is cut into ITEMS of up to
+    // kItem consecutive points of one segment so that every lane of the walk
+    // executes the same unrolled body.
+    const int nslots = total_pairs * kRows;
+    for (int sl = tid; sl < nslots; sl += kScoreThreads) {
+      const int q = sl / kRows, rr = sl - q * kRows;
+      const int* ri = reinterpret_cast<const int*>(rec + (size_t)q * rec_words);
+      const int cx0 = (short)(ri[18] & 0xFFFF), cx1 = ri[18] >> 16;
+      const int cy0 = (short)(ri[19] & 0xFFFF), cy1 = ri[19] >> 16;
+      const int cy = cy0 + rr;
+      uint32_t b = 0, len = 0;
+      if (cx0 <= cx1 && cy <= cy1) {
+        b = cell_start[(cy * k.gnx + cx0) * k.gnz];
+        len = cell_start[(cy * k.gnx + cx1 + 1) * k.gnz] - b;
       }
-      if (hit_box) atomicOr(&head[j].hit_box, 1);
-      if (hit_mm) atomicOr(&head[j].hit_mm, 1);
+      seg_p[sl] = b;
+      seg_len[sl] = len;
+    }
+    __syncthreads();
+    // exclusive scan of items per slot
+    uint32_t carry = 0;
+    for (int base = 0; base < nslots; base += kScoreThreads) {
+      const int sl = base + tid;
+      const uint32_t cnt = sl < nslots ? (seg_len[sl] + kItem - 1) / kItem : 0u;
+      uint32_t incl = cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
+      }
+      if (lane == 63) wsum[wid] = incl;
+      __syncthreads();
+      uint32_t wofs = 0, tot = 0;
+#pragma unroll
+      for (int wv = 0; wv < kScoreThreads / 64; ++wv) {
+        const uint32_t v = wsum[wv];
+        if (wv < wid) wofs += v;
+        tot += v;
+      }
+      if (sl < nslots) pref[sl] = carry + wofs + incl - cnt;
+      carry += tot;
+      __syncthreads();
+    }
+    if (tid == 0) pref[nslots] = carry;
+    __syncthreads();
+
+    // ---- phase D3: load-balanced item walk -----------------------------------
+    const uint32_t total = pref[nslots];
+    const uint32_t chunk = (total + kScoreThreads - 1) / kScoreThreads;
+    uint32_t it = (uint32_t)tid * chunk;
+    const uint32_t it1 = min(total, it + chunk);
+    if (it < it1) {
+      int lo = 0, hi = nslots;                      // largest slot with pref[slot] <= it
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (pref[mid] <= it) lo = mid; else hi = mid;
+      }
+      int sl = lo;
+      for (; it < it1; ++it) {
+        while (pref[sl + 1] <= it) ++sl;            // skip empty slots
+        const int q = sl / kRows;
+        const float* rq = rec + (size_t)q * rec_words;
+        const int j = reinterpret_cast<const int*>(rq)[20];
+        const bool hb = !need_box || head[j].hit_box != 0;
+        const bool hm = !need_mm || head[j].hit_mm != 0;
+        if (hb && hm) continue;                     // trajectory already decided
+        const uint32_t off = (it - pref[sl]) * kItem;
+        const uint32_t p0 = seg_p[sl] + off;
+        const uint32_t n = min((uint32_t)kItem, seg_len[sl] - off);
+        // kItem independent loads in flight (the sorted array is padded by kItem)
+        float4 pt[kItem];
+#pragma unroll
+        for (int u = 0; u < kItem; ++u) pt[u] = sorted[p0 + u];
+        float r[18];
+#pragma unroll
+        for (int u = 0; u < 18; ++u) r[u] = rq[u];
+        bool fb = false, fm = false;
+#pragma unroll
+        for (int u = 0; u < kItem; ++u) {
+          // radiusSearch(pose, 1.0): FLANN keeps dist^2 < r^2
+          const bool in = (uint32_t)u < n && l2_simple(r[15], r[16], r[17], pt[u].x, pt[u].y, pt[u].z) < 1.0f;
+          if (need_box) fb |= in && box_test(r, pt[u].x, pt[u].y, pt[u].z);
+          if (need_mm)
+            fm |= in && (pt[u].x >= rq[21] && pt[u].x <= rq[24] && pt[u].y >= rq[22] && pt[u].y <= rq[25] &&
+                         pt[u].z >= rq[23] && pt[u].z <= rq[26]);
+        }
+        if (fb) atomicOr(&head[j].hit_box, 1);
+        if (fm) atomicOr(&head[j].hit_mm, 1);
+      }
     }
   }
   __syncthreads();
@@ -520,7 +653,7 @@ __global__ __launch_bounds__(kScoreThreads) void k_score(
   int64_t key = kKeyNone;
   if (tid < nt) {
     const TrajHead h = head[tid];
-    const int li = t0 + tid;
+    const int li = (int)blockIdx.x + tid * n_tiles;
     const int gi = k.begin + li;
     double cost = DDDMR_COST_NOT_GENERATED;
     if (h.steps > 0) {

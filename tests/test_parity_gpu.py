@@ -93,7 +93,9 @@ def test_hip_matches_golden(name):
 def test_shipped_dd_on_c1_cloud():
     sc = scenes.bench_scene("C1")
     th = configs.dd_simple_shipped()
-    res, costs, o = against_oracle(th, sc.cloud, sc.plan, scenes.tick_input(twist=(0.4, 0.0, 0.1)))
+    post = np.array([[1.05, 0.45, z, 0.0] for z in np.arange(0.05, 1.0, 0.05)], dtype=np.float32)
+    cloud = np.concatenate([sc.cloud, post])
+    res, costs, o = against_oracle(th, cloud, sc.plan, scenes.tick_input(twist=(0.4, 0.0, 0.1)))
     assert res.n_samples == 55 and (costs == -1.0).any() and (costs >= 0).any()
 
 
