@@ -166,7 +166,9 @@ _lib = None
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", _LIB_NAME)
+    # DDDMR_LIB_NAME selects the diagnostic build (phase stamps) for tools/phase_stamps.py
+    name = os.environ.get("DDDMR_LIB_NAME", _LIB_NAME)
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", name)
 
 
 def load_library() -> C.CDLL:

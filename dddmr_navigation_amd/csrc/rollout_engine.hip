@@ -275,6 +275,13 @@ void tile_extent(const dddmr_theory_config& c, const Window& w, const double R[9
 
 extern "C" {
 
+#ifdef DDDMR_PHASE_STAMPS
+// diagnostic build only: copy the per-workgroup phase stamps of the last k_score launch
+int dddmr_rollout_diag_stamps(unsigned long long* out, size_t n_words) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n_words * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+
 const char* dddmr_rollout_version(void) { return "dddmr-rollout-mi355x 0.1 (gfx950)"; }
 
 size_t dddmr_rollout_sizeof(int which) {

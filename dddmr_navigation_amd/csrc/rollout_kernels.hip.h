@@ -229,6 +229,19 @@ __global__ __launch_bounds__(256) void k_bin_scatter(DevTick k, const float4* __
 //      item list; trajectory-level early exit through LDS flags
 //   E  stacked scoring + packed-key wave min-reduction + one atomicMin
 // ---------------------------------------------------------------------------
+// Diagnostic build only (make diag): per-workgroup phase timestamps, written to a
+// buffer nothing else reads (cdna_hip_programming.md 7, In-kernel stamps).
+#ifdef DDDMR_PHASE_STAMPS
+constexpr int kStampSlots = 10;
+__device__ unsigned long long g_stamps[16384 * kStampSlots];
+#define DDDMR_STAMP(i)                                                                         \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * kStampSlots + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define DDDMR_STAMP(i) do { } while (0)
+#endif
+
 struct TrajHead {     // per-trajectory header in LDS
   float vx, vy, w;
   int steps;          // 0 = not generated
@@ -245,6 +258,7 @@ constexpr int kRecWords = 21;       // odd stride: conflict-free field reads acr
 constexpr int kRecWordsMM = 27;     // + world AABB for CollisionMinMaxModel
 constexpr int kRows = 8;            // y-rows of cells one cuboid AABB may span (host sizes the cells for it)
 constexpr int kItem = 8;            // points per work item of the collision walk
+constexpr int kTabCap = 4096;       // (gnx+1)*gny row-run boundaries staged in LDS when they fit
 
 // dynamic LDS carve, see k_score (rows are max_steps+1 long):
 __host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m, bool omni, bool want_mm) {
@@ -254,13 +268,15 @@ __host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m
   b += sizeof(TrajHead) * (size_t)tile;
   b = (b + 15) & ~(size_t)15;
   b += 16 * (size_t)(m > 0 ? m : 1);                 // plan
-  b += 16 * (size_t)tile * S1 * (omni ? 2 : 1);      // sc (+ sc2 for omni)
+  b += 16 * (size_t)tile * S1 * 2;                   // sc (cos,sin of theta_k) + inc (x,y increments)
+  (void)omni;
   b += 4 * (size_t)tile * S1;                        // th
   b += 8 * (size_t)tile * S1;                        // xy
   b += 4 * (size_t)tile * S1;                        // dist
   b += 4 * (size_t)(want_mm ? kRecWordsMM : kRecWords) * Q;   // OBB records
   b += 4 * (Q * kRows + 1);                          // item prefix sums per (pair,row) slot
   b += 8 * (Q * kRows);                              // segment start + length per slot
+  b += 4 * (size_t)kTabCap;                          // costmap row-run index (cell_start slice)
   b += 64;                                           // scan scratch
   return (b + 15) & ~(size_t)15;
 }
@@ -294,11 +310,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   ofs += 16 * (size_t)(k.m > 0 ? k.m : 1);
   double2* sc = reinterpret_cast<double2*>(lds_raw + ofs);
   ofs += 16 * (size_t)tile * S1;
-  double2* sc2 = sc;
-  if (omni) {
-    sc2 = reinterpret_cast<double2*>(lds_raw + ofs);
-    ofs += 16 * (size_t)tile * S1;
-  }
+  double2* inc = reinterpret_cast<double2*>(lds_raw + ofs);   // body-frame position increments per step
+  ofs += 16 * (size_t)tile * S1;
   float* th = reinterpret_cast<float*>(lds_raw + ofs);
   ofs += 4 * (size_t)tile * S1;
   float2* xy = reinterpret_cast<float2*>(lds_raw + ofs);
@@ -313,7 +326,10 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   ofs += 4 * (size_t)Qcap * kRows;
   uint32_t* seg_len = reinterpret_cast<uint32_t*>(lds_raw + ofs);
   ofs += 4 * (size_t)Qcap * kRows;
-  uint32_t* wsum = reinterpret_cast<uint32_t*>(lds_raw + ofs);
+  uint32_t* tab = reinterpret_cast<uint32_t*>(lds_raw + ofs);
+  ofs += 4 * (size_t)kTabCap;
+  ofs = (ofs + 7) & ~(size_t)7;
+  unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(lds_raw + ofs);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -324,6 +340,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   const int n_tiles = gridDim.x;
   const int nt = (k.n_local - (int)blockIdx.x + n_tiles - 1) / n_tiles;   // <= tile
 
+  DDDMR_STAMP(0);
   // ---- stage the prune plan (float xyz, model_shared_data.h:83-91) ----
   for (int i = tid; i < k.m; i += kScoreThreads) plan[i] = plan_xyz[i];
 
@@ -400,6 +417,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   }
   __syncthreads();
 
+  DDDMR_STAMP(1);   // end of phase A
   // pair offsets (tile <= 16: serial prefix by one lane)
   if (tid == 0) {
     int acc = 0;
@@ -412,45 +430,62 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   // ---- phase B: double sin/cos of every theta_k (k = 0..steps), all lanes ----
   // theta_k feeds the next position update (cos/sin of the float state) and the
   // pose's AngleAxisd(theta) rotation (dd_simple...cpp:416); the omni theory also
-  // needs cos/sin(M_PI_2 + theta) in double (omni_simple...cpp:501-502).
+  // needs cos/sin(M_PI_2 + theta) in double (omni_simple...cpp:501-502).  The
+  // body-frame position increment of step k, (v cos, v sin)(theta_k) * dt, only
+  // depends on theta_k, so it is formed here too and phase C is a bare running sum.
+  // The costmap's row-run index is staged meanwhile (independent loads).
+  const int tab_n = (k.gnx + 1) * k.gny;
+  const bool tab_staged = tab_n <= kTabCap;
+  if (tab_staged && k.n_points >= 5 && (need_box || need_mm)) {
+    for (int i = tid; i < tab_n; i += kScoreThreads) {
+      const int cy = i / (k.gnx + 1), cx = i - cy * (k.gnx + 1);
+      tab[i] = cell_start[(cy * k.gnx + cx) * k.gnz];
+    }
+  }
   for (int idx = tid; idx < nt * S1; idx += kScoreThreads) {
     const int j = idx / S1, s = idx - j * S1;
-    if (s <= head[j].steps) {
+    const TrajHead& h = head[j];
+    if (s <= h.steps) {
       const double a = (double)th[(size_t)j * S1 + s];
       double sn, cs;
       sincos(a, &sn, &cs);
       sc[(size_t)j * S1 + s] = make_double2(cs, sn);
-      if (omni) {
-        sincos(M_PI_2 + a, &sn, &cs);
-        sc2[(size_t)j * S1 + s] = make_double2(cs, sn);
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- phase C: x,y recurrence in the body frame ----
-  if (tid < nt) {
-    const TrajHead h = head[tid];
-    const double2* scr = sc + (size_t)tid * S1;
-    const double2* scr2 = sc2 + (size_t)tid * S1;
-    float2* xr = xy + (size_t)tid * S1;
-    float px = 0.f, py = 0.f;
-    for (int s = 0; s < h.steps; ++s) {
-      const double2 cs = scr[s];
-      const float cf = (float)cs.x, sf = (float)cs.y;  // cos/sin(float) overloads
+      const float cf = (float)cs, sf = (float)sn;      // cos/sin(float) overloads
       double ix = (double)fmul(h.vx, cf), iy = (double)fmul(h.vx, sf);
       if (omni) {
-        const double2 c2 = scr2[s];
-        ix += (double)h.vy * c2.x;
-        iy += (double)h.vy * c2.y;
+        double s2, c2;
+        sincos(M_PI_2 + a, &s2, &c2);
+        ix += (double)h.vy * c2;
+        iy += (double)h.vy * s2;
       }
-      px = (float)((double)px + ix * h.dt);
-      py = (float)((double)py + iy * h.dt);
-      xr[s] = make_float2(px, py);
+      inc[(size_t)j * S1 + s] = make_double2(ix * h.dt, iy * h.dt);
     }
   }
   __syncthreads();
 
+  DDDMR_STAMP(2);   // end of phase B
+  // ---- phase C: x,y recurrence in the body frame: p = float(double(p) + inc) ----
+  if (tid < nt) {
+    const int ns = head[tid].steps;
+    const double2* ir = inc + (size_t)tid * S1;
+    float2* xr = xy + (size_t)tid * S1;
+    float px = 0.f, py = 0.f;
+    int s = 0;
+    for (; s + 4 <= ns; s += 4) {
+      const double2 i0 = ir[s], i1 = ir[s + 1], i2 = ir[s + 2], i3 = ir[s + 3];
+      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); xr[s] = make_float2(px, py);
+      px = (float)((double)px + i1.x); py = (float)((double)py + i1.y); xr[s + 1] = make_float2(px, py);
+      px = (float)((double)px + i2.x); py = (float)((double)py + i2.y); xr[s + 2] = make_float2(px, py);
+      px = (float)((double)px + i3.x); py = (float)((double)py + i3.y); xr[s + 3] = make_float2(px, py);
+    }
+    for (; s < ns; ++s) {
+      const double2 i0 = ir[s];
+      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); xr[s] = make_float2(px, py);
+    }
+  }
+  __syncthreads();
+
+  DDDMR_STAMP(3);   // end of phase C
   // ---- phase D1: one (trajectory, step) pair per lane ----
   int total_pairs = 0;
   if (nt > 0) total_pairs = head[nt - 1].pair_base + head[nt - 1].steps;
@@ -478,7 +513,14 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     // ---- path critics: exact 1-NN distance to the prune plan ----
     {
       float best = 3.402823466e+38f;
-      for (int i = 0; i < k.m; ++i) {
+      int i = 0;
+      for (; i + 4 <= k.m; i += 4) {
+        const float4 p0 = plan[i], p1 = plan[i + 1], p2 = plan[i + 2], p3 = plan[i + 3];
+        const float d0 = l2_simple(p0.x, p0.y, p0.z, px, py, pz), d1 = l2_simple(p1.x, p1.y, p1.z, px, py, pz);
+        const float d2 = l2_simple(p2.x, p2.y, p2.z, px, py, pz), d3 = l2_simple(p3.x, p3.y, p3.z, px, py, pz);
+        best = fminf(fminf(best, fminf(d0, d1)), fminf(d2, d3));
+      }
+      for (; i < k.m; ++i) {
         const float4 pp = plan[i];
         best = fminf(best, l2_simple(pp.x, pp.y, pp.z, px, py, pz));
       }
@@ -552,6 +594,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   }
   __syncthreads();
 
+  DDDMR_STAMP(4);   // end of phase D1
   if (do_coll && total_pairs > 0) {
     // ---- phase D2: row segments per pair -----------------------------------
     // z is the fastest cell axis, then x: the cells [cx0..cx1] x all z of one y-row
@@ -560,71 +603,90 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     // kItem consecutive points of one segment so that every lane of the walk
     // executes the same unrolled body.
     const int nslots = total_pairs * kRows;
-    for (int sl = tid; sl < nslots; sl += kScoreThreads) {
-      const int q = sl / kRows, rr = sl - q * kRows;
-      const int* ri = reinterpret_cast<const int*>(rec + (size_t)q * rec_words);
-      const int cx0 = (short)(ri[18] & 0xFFFF), cx1 = ri[18] >> 16;
-      const int cy0 = (short)(ri[19] & 0xFFFF), cy1 = ri[19] >> 16;
-      const int cy = cy0 + rr;
-      uint32_t b = 0, len = 0;
-      if (cx0 <= cx1 && cy <= cy1) {
-        b = cell_start[(cy * k.gnx + cx0) * k.gnz];
-        len = cell_start[(cy * k.gnx + cx1 + 1) * k.gnz] - b;
-      }
-      seg_p[sl] = b;
-      seg_len[sl] = len;
-    }
-    __syncthreads();
-    // exclusive scan of items per slot
-    uint32_t carry = 0;
+    // One packed 64-bit exclusive scan gives, per (pair,row) slot, both the index
+    // of the slot among the NON-EMPTY ones (high word) and the number of items in
+    // front of it (low word); empty slots (open space: most of them) are dropped so
+    // the walk never has to step over them.
+    unsigned long long carry = 0;
     for (int base = 0; base < nslots; base += kScoreThreads) {
       const int sl = base + tid;
-      const uint32_t cnt = sl < nslots ? (seg_len[sl] + kItem - 1) / kItem : 0u;
-      uint32_t incl = cnt;
+      uint32_t b = 0, len = 0;
+      int q = 0;
+      if (sl < nslots) {
+        q = sl / kRows;
+        const int rr = sl - q * kRows;
+        const int* ri = reinterpret_cast<const int*>(rec + (size_t)q * rec_words);
+        const int cx0 = (short)(ri[18] & 0xFFFF), cx1 = ri[18] >> 16;
+        const int cy0 = (short)(ri[19] & 0xFFFF), cy1 = ri[19] >> 16;
+        const int cy = cy0 + rr;
+        if (cx0 <= cx1 && cy <= cy1) {
+          if (tab_staged) {
+            b = tab[cy * (k.gnx + 1) + cx0];
+            len = tab[cy * (k.gnx + 1) + cx1 + 1] - b;
+          } else {
+            b = cell_start[(cy * k.gnx + cx0) * k.gnz];
+            len = cell_start[(cy * k.gnx + cx1 + 1) * k.gnz] - b;
+          }
+        }
+      }
+      const unsigned long long cnt = len ? ((1ull << 32) | (unsigned long long)((len + kItem - 1) / kItem)) : 0ull;
+      unsigned long long incl = cnt;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, 64);
+        const unsigned long long up = __shfl_up(incl, o, 64);
         if (lane >= o) incl += up;
       }
-      if (lane == 63) wsum[wid] = incl;
+      if (lane == 63) wsum64[wid] = incl;
       __syncthreads();
-      uint32_t wofs = 0, tot = 0;
+      unsigned long long wofs = 0, tot = 0;
 #pragma unroll
       for (int wv = 0; wv < kScoreThreads / 64; ++wv) {
-        const uint32_t v = wsum[wv];
+        const unsigned long long v = wsum64[wv];
         if (wv < wid) wofs += v;
         tot += v;
       }
-      if (sl < nslots) pref[sl] = carry + wofs + incl - cnt;
+      if (len) {
+        const unsigned long long ex = carry + wofs + incl - cnt;
+        const uint32_t ci = (uint32_t)(ex >> 32);
+        pref[ci] = (uint32_t)ex;
+        seg_p[ci] = b;
+        seg_len[ci] = (len << 12) | (uint32_t)q;     // pair index < 4096, run length < 2^20
+      }
       carry += tot;
       __syncthreads();
     }
-    if (tid == 0) pref[nslots] = carry;
+    const int nseg = (int)(carry >> 32);
+    const uint32_t total = (uint32_t)carry;
+    if (tid == 0) pref[nseg] = total;
     __syncthreads();
 
+    DDDMR_STAMP(5);   // end of phase D2
     // ---- phase D3: load-balanced item walk -----------------------------------
-    const uint32_t total = pref[nslots];
+#ifdef DDDMR_PHASE_STAMPS
+    if (tid == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * kStampSlots + 9] = total;
+#endif
     const uint32_t chunk = (total + kScoreThreads - 1) / kScoreThreads;
     uint32_t it = (uint32_t)tid * chunk;
     const uint32_t it1 = min(total, it + chunk);
     if (it < it1) {
-      int lo = 0, hi = nslots;                      // largest slot with pref[slot] <= it
+      int lo = 0, hi = nseg;                        // largest segment with pref[seg] <= it
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
         if (pref[mid] <= it) lo = mid; else hi = mid;
       }
-      int sl = lo;
+      int sg = lo;
       for (; it < it1; ++it) {
-        while (pref[sl + 1] <= it) ++sl;            // skip empty slots
-        const int q = sl / kRows;
+        while (pref[sg + 1] <= it) ++sg;
+        const uint32_t sl_len = seg_len[sg];
+        const int q = (int)(sl_len & 0xFFFu);
         const float* rq = rec + (size_t)q * rec_words;
         const int j = reinterpret_cast<const int*>(rq)[20];
         const bool hb = !need_box || head[j].hit_box != 0;
         const bool hm = !need_mm || head[j].hit_mm != 0;
         if (hb && hm) continue;                     // trajectory already decided
-        const uint32_t off = (it - pref[sl]) * kItem;
-        const uint32_t p0 = seg_p[sl] + off;
-        const uint32_t n = min((uint32_t)kItem, seg_len[sl] - off);
+        const uint32_t off = (it - pref[sg]) * kItem;
+        const uint32_t p0 = seg_p[sg] + off;
+        const uint32_t n = min((uint32_t)kItem, (sl_len >> 12) - off);
         // kItem independent loads in flight (the sorted array is padded by kItem)
         float4 pt[kItem];
 #pragma unroll
@@ -649,6 +711,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   }
   __syncthreads();
 
+  DDDMR_STAMP(6);   // end of phase D3
   // ---- phase E: stacked scoring (stacked_scoring_model.cpp:75-93) + argmin ----
   int64_t key = kKeyNone;
   if (tid < nt) {
@@ -672,8 +735,15 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
             if (k.m < 3) {
               r = 10.0;
             } else {
-              double acc = 0.0;
-              for (int s = 0; s < h.steps; ++s) acc += (double)dr[s];
+              double acc = 0.0;      // summed in step order like the reference's loop
+              int s = 0;
+              for (; s + 8 <= h.steps; s += 8) {
+                const float d0 = dr[s], d1 = dr[s + 1], d2 = dr[s + 2], d3 = dr[s + 3];
+                const float d4 = dr[s + 4], d5 = dr[s + 5], d6 = dr[s + 6], d7 = dr[s + 7];
+                acc += (double)d0; acc += (double)d1; acc += (double)d2; acc += (double)d3;
+                acc += (double)d4; acc += (double)d5; acc += (double)d6; acc += (double)d7;
+              }
+              for (; s < h.steps; ++s) acc += (double)dr[s];
               r = acc / (double)k.m;
             }
             break;
@@ -714,6 +784,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     }
     if (tid == 0 && key != kKeyNone) atomicMin((long long*)best_key, (long long)key);
   }
+  DDDMR_STAMP(7);
 }
 
 __global__ void k_finalize(DevTick k, const int64_t* __restrict__ best_key,

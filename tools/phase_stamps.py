@@ -1,0 +1,36 @@
+"""Per-workgroup phase breakdown of k_score from the diagnostic build
+(make -C dddmr_navigation_amd/csrc diag).  Shares, not run time, are meaningful.
+usage: DDDMR_LIB_NAME=libdddmr_rollout_diag.so python tools/phase_stamps.py C2"""
+import ctypes as C, sys
+import numpy as np
+from dddmr_navigation_amd import scenes, _capi as K
+from dddmr_navigation_amd.local_planner import LocalPlanner
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
+sc = scenes.bench_scene(cfg)
+lib = K.load_library()
+with LocalPlanner([sc.theory], max_points=len(sc.cloud)) as lp:
+    lp.set_cloud(sc.cloud); lp.setPlan(sc.plan)
+    name = sc.theory.name.decode()
+    for _ in range(5):
+        r = lp.tick(name, sc.tick)
+    SL = 10
+    n_wg = 16384
+    buf = np.zeros(n_wg * SL, dtype=np.uint64)
+    lib.dddmr_rollout_diag_stamps.argtypes = [C.c_void_p, C.c_size_t]
+    assert lib.dddmr_rollout_diag_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
+    st = buf.reshape(n_wg, SL)
+    used = st[:, 7] > 0
+    st = st[used].astype(np.int64)
+    print(cfg, "workgroups", len(st), "score_ms", r.score_ms)
+    names = ["A theta", "B trig+index", "C xy", "D1 pose/path/obb", "D2 segments+scan", "D3 walk", "E score"]
+    t0 = st[:, 0].min()
+    for i, nm in enumerate(names):
+        d = (st[:, i + 1] - st[:, i]) / 100.0   # s_memtime ticks at 100 MHz -> us
+        print(f"  {nm:18s} mean {d.mean():8.2f} us  p50 {np.percentile(d,50):8.2f}  p99 {np.percentile(d,99):8.2f}  max {d.max():8.2f}")
+    life = (st[:, 7] - st[:, 0]) / 100.0
+    print(f"  workgroup lifetime mean {life.mean():.2f} us max {life.max():.2f} us; first start -> last end {(st[:,7].max()-t0)/100.0:.2f} us")
+    start = (st[:, 0] - t0) / 100.0
+    print(f"  start times: p50 {np.percentile(start,50):.2f} p90 {np.percentile(start,90):.2f} max {start.max():.2f} us")
+    tot = st[:, 9]
+    print(f"  items per wg: mean {tot.mean():.0f} max {tot.max()}  corr(items, D3 time) {np.corrcoef(tot, st[:,6]-st[:,5])[0,1]:.3f}")
