@@ -169,7 +169,8 @@ struct dddmr_rollout_ctx {
   float4* samples_out = nullptr;
   int64_t* best_key = nullptr;
   uint32_t* overflow = nullptr;
-  DevResult* result_dev = nullptr;
+  DevResult* result_dev = nullptr;   // device alias of result_host (host-mapped)
+  uint32_t* tickets = nullptr;       // [0] binning ticket, [1] scoring ticket
   double* poses_dev = nullptr;
   // perception feed scratch
   PerceptionScratch feed{};
@@ -314,7 +315,7 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   }
   void* dev[] = {ctx->pt_slot, ctx->sorted, ctx->cell_count, ctx->cell_start, ctx->axes_dev,
                  ctx->samples_dev, ctx->plan_dev, ctx->costs, ctx->steps, ctx->samples_out,
-                 ctx->best_key, ctx->overflow, ctx->result_dev, ctx->poses_dev};
+                 ctx->best_key, ctx->overflow, ctx->tickets, ctx->poses_dev};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   perception_free(ctx->feed);
@@ -386,13 +387,15 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMalloc(&ctx->samples_out, N * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&ctx->best_key, sizeof(int64_t)));
     HIPCHK(ctx, hipMalloc(&ctx->overflow, sizeof(uint32_t)));
-    HIPCHK(ctx, hipMalloc(&ctx->result_dev, sizeof(DevResult)));
+    HIPCHK(ctx, hipMalloc(&ctx->tickets, 2 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(ctx->tickets, 0, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->poses_dev, (size_t)cfg->max_steps * 7 * sizeof(double)));
     HIPCHK(ctx, hipHostMalloc(&ctx->cloud_stage, P * sizeof(float4), hipHostMallocDefault));
     const size_t small = std::max<size_t>({3 * kMaxAxis * sizeof(float), N * sizeof(float4),
                                            plan_cap * sizeof(float4)});
     HIPCHK(ctx, hipHostMalloc(&ctx->small_stage, small, hipHostMallocDefault));
-    HIPCHK(ctx, hipHostMalloc(&ctx->result_host, sizeof(DevResult), hipHostMallocDefault));
+    HIPCHK(ctx, hipHostMalloc(&ctx->result_host, sizeof(DevResult), hipHostMallocMapped));
+    HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->result_dev), ctx->result_host, 0));
     const int rc = perception_alloc(ctx->feed, P);
     if (rc != 0) return fail(ctx, DDDMR_ERR_HIP, "perception scratch allocation failed");
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
@@ -624,15 +627,6 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
     return fail(ctx, DDDMR_ERR_CAPACITY, "horizon of %d steps > max_steps %u", s_tick, ctx->cfg.max_steps);
   k.max_steps = s_tick;
 
-  // trajectories per workgroup: ~one (trajectory, step) pair per lane
-  int tile = ctx->tile_override > 0 ? ctx->tile_override : kScoreThreads / s_tick;
-  tile = std::min(std::max(tile, 1), kMaxTile);
-  const bool is_omni = th->kind == DDDMR_THEORY_OMNI_SIMPLE;
-  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0) > 72 * 1024) --tile;
-  const size_t lds = score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0);
-  if (lds > (size_t)kScoreLdsMax) return fail(ctx, DDDMR_ERR_CAPACITY, "horizon needs %zu bytes of LDS", lds);
-  k.tile = tile;
-
   // ---- cloud front buffer + local costmap tile ----
   int cidx;
   bool pending;
@@ -673,11 +667,34 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   k.inv_cell = 1.0f / cell;
   for (int i = 0; i < 3; ++i) k.gmin[i] = k.rmin[i];
 
+  // trajectories per workgroup: ~one (trajectory, step) pair per lane
+  // ~160 pairs per 256-thread workgroup measured best on MI355X (C2: tile 3, C3: tile 2):
+  // smaller LDS footprint -> more resident workgroups to cover the serial phases
+  int tile = ctx->tile_override > 0 ? ctx->tile_override : (160 + s_tick / 2) / s_tick;
+  tile = std::min(std::max(tile, 1), kMaxTile);
+  const bool is_omni = th->kind == DDDMR_THEORY_OMNI_SIMPLE;
+  {
+    const long te = (long)(k.gnx + 1) * k.gny;
+    k.tab_entries = (te <= kTabCap && k.n_points >= 5 && (k.want_collision || k.want_minmax)) ? (int)te : 0;
+  }
+  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0, k.tab_entries) > 72 * 1024) --tile;
+  const size_t lds = score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0, k.tab_entries);
+  if (lds > (size_t)kScoreLdsMax) return fail(ctx, DDDMR_ERR_CAPACITY, "horizon needs %zu bytes of LDS", lds);
+  k.tile = tile;
+
+
   if (k.n_local > 0) {
     // small per-tick uploads (sample axes or explicit list)
     if (w.list_mode) {
       std::memcpy(ctx->small_stage, w.list.data(), N * sizeof(float4));
       HIPCHK(ctx, hipMemcpyAsync(ctx->samples_dev, ctx->small_stage, N * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    } else if (w.ax.size() + w.ay.size() + w.ath.size() <= (size_t)kInlineAxes) {
+      k.axes_inline = 1;                      // axes ride in the kernel arguments
+      k.ay_ofs = (int)w.ax.size();
+      k.ath_ofs = (int)(w.ax.size() + w.ay.size());
+      std::memcpy(k.axes_inl, w.ax.data(), w.ax.size() * sizeof(float));
+      std::memcpy(k.axes_inl + k.ay_ofs, w.ay.data(), w.ay.size() * sizeof(float));
+      std::memcpy(k.axes_inl + k.ath_ofs, w.ath.data(), w.ath.size() * sizeof(float));
     } else {
       float* a = ctx->small_stage;
       std::memcpy(a, w.ax.data(), w.ax.size() * sizeof(float));
@@ -690,26 +707,26 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
 
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const int bin_blocks = std::max(1, std::min(2048, (k.n_points + 255) / 256));
-  if (k.n_points > 0)
+  if (k.n_points > 0) {
     hipLaunchKernelGGL(k_bin_count, dim3(bin_blocks), dim3(256), 0, ctx->stream, k, ctx->cloud_dev[cidx],
-                       ctx->cell_count, ctx->pt_slot);
-  hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, ctx->stream, k, ctx->cell_count, ctx->cell_start,
-                     ctx->best_key, ctx->overflow);
-  if (k.n_points > 0)
+                       ctx->cell_count, ctx->cell_start, ctx->pt_slot, ctx->tickets, ctx->best_key, ctx->overflow);
     hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks), dim3(256), 0, ctx->stream, k, ctx->cloud_dev[cidx],
                        ctx->pt_slot, ctx->cell_start, ctx->sorted);
+  } else {
+    hipLaunchKernelGGL(k_bin_reset, dim3(1), dim3(256), 0, ctx->stream, k, ctx->cell_count, ctx->cell_start,
+                       ctx->best_key, ctx->overflow);
+  }
   HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
   if (k.n_local > 0) {
     const int wgs = (k.n_local + tile - 1) / tile;
     hipLaunchKernelGGL(k_score, dim3(wgs), dim3(kScoreThreads), lds, ctx->stream, k, ctx->axes_dev,
                        ctx->samples_dev, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
-                       ctx->samples_out, ctx->best_key, ctx->overflow);
+                       ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev);
+  } else {
+    hipLaunchKernelGGL(k_empty_result, dim3(1), dim3(64), 0, ctx->stream, k, ctx->cell_start, ctx->result_dev);
   }
   HIPCHK(ctx, hipEventRecord(ctx->evs1, ctx->stream));
-  hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, ctx->stream, k, ctx->best_key, ctx->costs,
-                     ctx->samples_out, ctx->cell_start, ctx->overflow, ctx->result_dev);
   HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIPCHK(ctx, hipMemcpyAsync(ctx->result_host, ctx->result_dev, sizeof(DevResult), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipGetLastError());
   float ms = 0.f;

@@ -1,14 +1,15 @@
 // rollout_kernels.hip.h -- CDNA4 (gfx950) kernels of the local-planner tick.
 //
-// One tick = 5 launches on one stream:
-//   k_bin_count  : crop the aggregate cloud to the local costmap tile and count
-//                  points per cell               (replaces the per-tick kd-tree
-//                  build, mpc_critics/include/mpc_critics/model_shared_data.h:78-81)
-//   k_bin_scan   : exclusive scan of the cell counts (one workgroup)
+// One tick = 3 launches on one stream:
+//   k_bin_count  : crop the aggregate cloud to the local costmap tile, count
+//                  points per cell; the last workgroup scans the counters
+//                  (replaces the per-tick kd-tree build,
+//                  mpc_critics/include/mpc_critics/model_shared_data.h:78-81)
 //   k_bin_scatter: counting-sort scatter -> cell-sorted float4 points
 //   k_score      : fused rollout (trajectory_generators theories) + all critics
-//                  (mpc_critics/models/*.cpp) + per-workgroup argmin
-//   k_finalize   : decode the winner (local_planner.cpp:447-480)
+//                  (mpc_critics/models/*.cpp) + packed-key argmin; the last
+//                  workgroup decodes the winner (local_planner.cpp:447-480)
+//                  into host-mapped memory
 //
 // No MFMA anywhere: this is gather / compare work.
 //
@@ -31,6 +32,7 @@ namespace dddmr {
 constexpr int kScoreThreads = 256;
 constexpr int kMaxTile = 16;          // trajectories per workgroup (upper bound)
 constexpr int kMaxPlan = 512;         // prune-plan poses kept in LDS
+constexpr int kInlineAxes = 192;      // sample-axis floats that travel inside the kernel arguments
 constexpr int64_t kKeyNone = INT64_MAX;
 constexpr int kKeyIndexBits = 24;     // 16.7 M samples per tick
 
@@ -71,9 +73,14 @@ struct DevTick {
   float rmin[3], rmax[3];   // region accepted by the binning pass
   int tile;          // trajectories per workgroup
   int want_collision, want_minmax;
+  int tab_entries;   // row-run index entries staged in LDS by k_score (0 = read from L2)
+  // sample axes inline in the kernarg segment when they fit (no per-tick H2D copy):
+  // x at [0,nx), y at [nx,nx+ny), theta at [nx+ny, nx+ny+nth)
+  int axes_inline;
+  float axes_inl[kInlineAxes];
 };
 
-struct DevResult {    // written by k_finalize, copied to the host
+struct DevResult {    // written by the last k_score workgroup into host-mapped memory
   int64_t key;
   double cost;
   float vx, vy, wz;
@@ -132,9 +139,65 @@ __device__ __forceinline__ int cell_of(const DevTick& k, float x, float y, float
   return (cy * k.gnx + cx) * k.gnz + cz;
 }
 
+// Exclusive scan of the cell counters by ONE workgroup (any size that is a
+// multiple of 64, <= 1024); also zeroes the counters for the next tick.
+__device__ inline void scan_cells(const DevTick& k, uint32_t* __restrict__ cell_count,
+                                  uint32_t* __restrict__ cell_start, uint32_t* wave_sum, uint32_t* carry_s) {
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
+  if (tid == 0) *carry_s = 0;
+  __syncthreads();
+  const int n = k.n_cells;
+  for (int base = 0; base < n; base += nthr * 4) {
+    const int i0 = base + tid * 4;
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // counters were built with device-scope atomics by workgroups on any XCD
+      v[j] = (i0 + j < n) ? __hip_atomic_load(&cell_count[i0 + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+      if (i0 + j < n) cell_count[i0 + j] = 0u;
+    }
+    const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wave_sum[wid] = incl;
+    __syncthreads();
+    uint32_t wofs = 0, total = 0;
+    for (int w = 0; w < nw; ++w) {
+      const uint32_t x = wave_sum[w];
+      if (w < wid) wofs += x;
+      total += x;
+    }
+    const uint32_t carry = *carry_s;
+    uint32_t run = carry + wofs + incl - tsum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (i0 + j < n) cell_start[i0 + j] = run;
+      run += v[j];
+    }
+    __syncthreads();
+    if (tid == 0) *carry_s = carry + total;
+    __syncthreads();
+  }
+  if (tid == 0) cell_start[n] = *carry_s;
+}
+
+// Crop the cloud to the local costmap tile and count points per cell; the LAST
+// workgroup to finish (device-scope ticket) scans the counters, so binning is two
+// launches, not three.  Also resets the argmin key / capacity flag of the tick.
 __global__ __launch_bounds__(256) void k_bin_count(DevTick k, const float4* __restrict__ cloud,
                                                    uint32_t* __restrict__ cell_count,
-                                                   uint2* __restrict__ pt_slot) {
+                                                   uint32_t* __restrict__ cell_start,
+                                                   uint2* __restrict__ pt_slot, uint32_t* __restrict__ ticket,
+                                                   int64_t* __restrict__ best_key,
+                                                   uint32_t* __restrict__ overflow) {
+  __shared__ uint32_t wave_sum[16];
+  __shared__ uint32_t carry_s;
+  __shared__ uint32_t is_last;
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k.n_points; i += stride) {
     const float4 p = cloud[i];
@@ -148,58 +211,38 @@ __global__ __launch_bounds__(256) void k_bin_count(DevTick k, const float4* __re
     }
     pt_slot[i] = slot;
   }
+  // ticket: every wave drains its atomics, then one device-scope add per workgroup
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == gridDim.x - 1) ? 1u : 0u;
+    if (is_last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *ticket = 0;            // next tick
+      *best_key = kKeyNone;
+      *overflow = 0;
+    }
+  }
+  __syncthreads();
+  if (is_last) scan_cells(k, cell_count, cell_start, wave_sum, &carry_s);
 }
 
-// one workgroup of 1024 threads; also zeroes the counters for the next tick and
-// resets the argmin key.
-__global__ __launch_bounds__(1024) void k_bin_scan(DevTick k, uint32_t* __restrict__ cell_count,
+// Empty cloud: only the scan/reset part.
+__global__ __launch_bounds__(256) void k_bin_reset(DevTick k, uint32_t* __restrict__ cell_count,
                                                    uint32_t* __restrict__ cell_start,
                                                    int64_t* __restrict__ best_key,
                                                    uint32_t* __restrict__ overflow) {
   __shared__ uint32_t wave_sum[16];
   __shared__ uint32_t carry_s;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wid = tid >> 6;
-  if (tid == 0) {
-    carry_s = 0;
+  if (threadIdx.x == 0) {
     *best_key = kKeyNone;
     *overflow = 0;
   }
-  __syncthreads();
-  const int n = k.n_cells;
-  for (int base = 0; base < n; base += 1024 * 4) {
-    const int i0 = base + tid * 4;
-    uint32_t v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      v[j] = (i0 + j < n) ? cell_count[i0 + j] : 0u;
-      if (i0 + j < n) cell_count[i0 + j] = 0u;
-    }
-    const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
-    uint32_t incl = tsum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
-    if (lane == 63) wave_sum[wid] = incl;
-    __syncthreads();
-    uint32_t wofs = 0;
-    for (int w = 0; w < wid; ++w) wofs += wave_sum[w];
-    uint32_t total = 0;
-    for (int w = 0; w < 16; ++w) total += wave_sum[w];
-    const uint32_t carry = carry_s;
-    uint32_t run = carry + wofs + incl - tsum;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if (i0 + j < n) cell_start[i0 + j] = run;
-      run += v[j];
-    }
-    __syncthreads();
-    if (tid == 0) carry_s = carry + total;
-    __syncthreads();
-  }
-  if (tid == 0) cell_start[n] = carry_s;
+  scan_cells(k, cell_count, cell_start, wave_sum, &carry_s);
 }
 
 __global__ __launch_bounds__(256) void k_bin_scatter(DevTick k, const float4* __restrict__ cloud,
@@ -261,7 +304,7 @@ constexpr int kItem = 8;            // points per work item of the collision wal
 constexpr int kTabCap = 4096;       // (gnx+1)*gny row-run boundaries staged in LDS when they fit
 
 // dynamic LDS carve, see k_score (rows are max_steps+1 long):
-__host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m, bool omni, bool want_mm) {
+__host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m, bool omni, bool want_mm, int tab_entries) {
   const size_t S1 = (size_t)max_steps + 1;
   const size_t Q = (size_t)tile * (size_t)max_steps;
   size_t b = 0;
@@ -276,7 +319,7 @@ __host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m
   b += 4 * (size_t)(want_mm ? kRecWordsMM : kRecWords) * Q;   // OBB records
   b += 4 * (Q * kRows + 1);                          // item prefix sums per (pair,row) slot
   b += 8 * (Q * kRows);                              // segment start + length per slot
-  b += 4 * (size_t)kTabCap;                          // costmap row-run index (cell_start slice)
+  b += 4 * (size_t)tab_entries;                      // costmap row-run index (cell_start slice), 0 = not staged
   b += 64;                                           // scan scratch
   return (b + 15) & ~(size_t)15;
 }
@@ -294,7 +337,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     DevTick k, const float* __restrict__ axes, const float4* __restrict__ samples,
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
     const float4* __restrict__ sorted, double* __restrict__ costs, int32_t* __restrict__ steps_out,
-    float4* __restrict__ samples_out, int64_t* __restrict__ best_key, uint32_t* __restrict__ overflow) {
+    float4* __restrict__ samples_out, int64_t* __restrict__ best_key, uint32_t* __restrict__ overflow,
+    uint32_t* __restrict__ ticket, DevResult* __restrict__ result) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tile = k.tile;
   const int S1 = k.max_steps + 1;
@@ -327,7 +371,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   uint32_t* seg_len = reinterpret_cast<uint32_t*>(lds_raw + ofs);
   ofs += 4 * (size_t)Qcap * kRows;
   uint32_t* tab = reinterpret_cast<uint32_t*>(lds_raw + ofs);
-  ofs += 4 * (size_t)kTabCap;
+  ofs += 4 * (size_t)k.tab_entries;
   ofs = (ofs + 7) & ~(size_t)7;
   unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(lds_raw + ofs);
 
@@ -357,9 +401,15 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       const int r = gi / k.nth;
       const int iy = r % k.ny;
       const int ix = r / k.ny;
-      vx = axes[ix];
-      vy = axes[k.ay_ofs + iy];
-      w = axes[k.ath_ofs + ith];
+      if (k.axes_inline) {
+        vx = k.axes_inl[ix];
+        vy = k.axes_inl[k.ay_ofs + iy];
+        w = k.axes_inl[k.ath_ofs + ith];
+      } else {
+        vx = axes[ix];
+        vy = axes[k.ay_ofs + iy];
+        w = axes[k.ath_ofs + ith];
+      }
     }
     const double eps = 1e-4;
     bool ok = true;
@@ -434,8 +484,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   // body-frame position increment of step k, (v cos, v sin)(theta_k) * dt, only
   // depends on theta_k, so it is formed here too and phase C is a bare running sum.
   // The costmap's row-run index is staged meanwhile (independent loads).
-  const int tab_n = (k.gnx + 1) * k.gny;
-  const bool tab_staged = tab_n <= kTabCap;
+  const int tab_n = k.tab_entries;          // (gnx+1)*gny, or 0 when the index does not fit
+  const bool tab_staged = tab_n > 0;
   if (tab_staged && k.n_points >= 5 && (need_box || need_mm)) {
     for (int i = tid; i < tab_n; i += kScoreThreads) {
       const int cy = i / (k.gnx + 1), cx = i - cy * (k.gnx + 1);
@@ -551,17 +601,22 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       float v[4][3];
       float mnx = 3.402823466e+38f, mny = mnx, mnz = mnx, mxx = -mnx, mxy = -mnx, mxz = -mnx;
       float ccx = 0.f, ccy = 0.f, ccz = 0.f;
-#pragma unroll
-      for (int vtx = 0; vtx < 8; ++vtx) {
+      auto world_vertex = [&](int vtx, float& wx, float& wy, float& wz) {
         const double cx = k.cub[3 * vtx + 0], cy = k.cub[3 * vtx + 1], cz = k.cub[3 * vtx + 2];
-        const float wx = (float)(L[0] * cx + L[1] * cy + L[2] * cz + T[0]);
-        const float wy = (float)(L[3] * cx + L[4] * cy + L[5] * cz + T[1]);
-        const float wz = (float)(L[6] * cx + L[7] * cy + L[8] * cz + T[2]);
-        if (vtx < 4) { v[vtx][0] = wx; v[vtx][1] = wy; v[vtx][2] = wz; }
+        wx = (float)(L[0] * cx + L[1] * cy + L[2] * cz + T[0]);
+        wy = (float)(L[3] * cx + L[4] * cy + L[5] * cz + T[1]);
+        wz = (float)(L[6] * cx + L[7] * cy + L[8] * cz + T[2]);
         mnx = fminf(mnx, wx); mxx = fmaxf(mxx, wx);
         mny = fminf(mny, wy); mxy = fmaxf(mxy, wy);
         mnz = fminf(mnz, wz); mxz = fmaxf(mxz, wz);
-        ccx = fadd(ccx, wx); ccy = fadd(ccy, wy); ccz = fadd(ccz, wz);
+        ccx = fadd(ccx, wx); ccy = fadd(ccy, wy); ccz = fadd(ccz, wz);   // centre sum in vertex order
+      };
+#pragma unroll
+      for (int vtx = 0; vtx < 4; ++vtx) world_vertex(vtx, v[vtx][0], v[vtx][1], v[vtx][2]);
+#pragma unroll 1
+      for (int vtx = 4; vtx < 8; ++vtx) {
+        float wx, wy, wz;
+        world_vertex(vtx, wx, wy, wz);
       }
       float* r = rec + (size_t)q * rec_words;
       r[0] = ccx / 8.f; r[1] = ccy / 8.f; r[2] = ccz / 8.f;
@@ -784,28 +839,58 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     }
     if (tid == 0 && key != kKeyNone) atomicMin((long long*)best_key, (long long)key);
   }
+  // ---- winner decode by the last workgroup (local_planner.cpp:447-480) ----
+  // Placement-independent hand-off: drain stores, barrier, agent-scope release,
+  // device-scope ticket; the workgroup that draws the last ticket acquires and
+  // writes the result straight into host-mapped memory (no finalize launch, no
+  // D2H copy).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      *ticket = 0;
+      DevResult r;
+      r.key = __hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      r.index = key_index(r.key);
+      r.cost = -1.0;
+      r.vx = r.vy = r.wz = 0.f;
+      if (r.index >= 0) {
+        const int li = r.index - k.begin;
+        const unsigned long long cb = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(costs) + li,
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.cost = __longlong_as_double((long long)cb);
+        const float* so = reinterpret_cast<const float*>(samples_out + li);
+        r.vx = __hip_atomic_load(so + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.vy = __hip_atomic_load(so + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.wz = __hip_atomic_load(so + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      r.n_binned = cell_start[k.n_cells];
+      r.overflow = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *result = r;
+      __threadfence_system();
+    }
+  }
   DDDMR_STAMP(7);
 }
 
-__global__ void k_finalize(DevTick k, const int64_t* __restrict__ best_key,
-                           const double* __restrict__ costs, const float4* __restrict__ samples_out,
-                           const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ overflow,
-                           DevResult* __restrict__ res) {
+// n_local == 0 (a rank without samples): result only.
+__global__ void k_empty_result(DevTick k, const uint32_t* __restrict__ cell_start,
+                               DevResult* __restrict__ res) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   DevResult r;
-  r.key = *best_key;
-  r.index = key_index(r.key);
+  r.key = kKeyNone;
+  r.index = -1;
   r.cost = -1.0;
   r.vx = r.vy = r.wz = 0.f;
-  if (r.index >= 0) {
-    const int li = r.index - k.begin;
-    r.cost = costs[li];
-    const float4 s = samples_out[li];
-    r.vx = s.x; r.vy = s.y; r.wz = s.z;
-  }
   r.n_binned = cell_start[k.n_cells];
-  r.overflow = *overflow;
+  r.overflow = 0;
   *res = r;
+  __threadfence_system();
 }
 
 // Poses of one trajectory for visualisation (local_planner.cpp:472-478 publishes
