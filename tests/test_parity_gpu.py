@@ -181,7 +181,8 @@ def test_ramp_pose_and_offset_world():
     sc = scenes.bench_scene("C1")
     q = scenes.quat_from_rpy(0.05, math.radians(-10.0), 0.3)
     c, s = math.cos(0.3), math.sin(0.3)
-    cloud = sc.cloud.copy()
+    post = np.array([[1.05, 0.45, z, 0.0] for z in np.arange(0.05, 1.0, 0.05)], dtype=np.float32)
+    cloud = np.concatenate([sc.cloud, post])
     xy = cloud[:, :2].copy()
     cloud[:, 0] = 50.0 + c * xy[:, 0] - s * xy[:, 1]
     cloud[:, 1] = -20.0 + s * xy[:, 0] + c * xy[:, 1]
