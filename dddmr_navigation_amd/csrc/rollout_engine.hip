@@ -707,8 +707,9 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
 
   HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const int bin_blocks = std::max(1, std::min(2048, (k.n_points + 255) / 256));
+  const int cnt_blocks = std::max(1, std::min(512, (k.n_points + kBinThreads - 1) / kBinThreads));
   if (k.n_points > 0) {
-    hipLaunchKernelGGL(k_bin_count, dim3(bin_blocks), dim3(256), 0, ctx->stream, k, ctx->cloud_dev[cidx],
+    hipLaunchKernelGGL(k_bin_count, dim3(cnt_blocks), dim3(kBinThreads), 0, ctx->stream, k, ctx->cloud_dev[cidx],
                        ctx->cell_count, ctx->cell_start, ctx->pt_slot, ctx->tickets, ctx->best_key, ctx->overflow);
     hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks), dim3(256), 0, ctx->stream, k, ctx->cloud_dev[cidx],
                        ctx->pt_slot, ctx->cell_start, ctx->sorted);

@@ -30,6 +30,7 @@ namespace dddmr {
 #define DDDMR_SCORE_WPE 2   // min waves per SIMD the register allocator must allow for k_score
 #endif
 constexpr int kScoreThreads = 256;
+constexpr int kBinThreads = 1024;     // k_bin_count workgroup (its last workgroup scans 4096 cells per step)
 constexpr int kMaxTile = 16;          // trajectories per workgroup (upper bound)
 constexpr int kMaxPlan = 512;         // prune-plan poses kept in LDS
 constexpr int kInlineAxes = 192;      // sample-axis floats that travel inside the kernel arguments
@@ -189,7 +190,7 @@ __device__ inline void scan_cells(const DevTick& k, uint32_t* __restrict__ cell_
 // Crop the cloud to the local costmap tile and count points per cell; the LAST
 // workgroup to finish (device-scope ticket) scans the counters, so binning is two
 // launches, not three.  Also resets the argmin key / capacity flag of the tick.
-__global__ __launch_bounds__(256) void k_bin_count(DevTick k, const float4* __restrict__ cloud,
+__global__ __launch_bounds__(kBinThreads) void k_bin_count(DevTick k, const float4* __restrict__ cloud,
                                                    uint32_t* __restrict__ cell_count,
                                                    uint32_t* __restrict__ cell_start,
                                                    uint2* __restrict__ pt_slot, uint32_t* __restrict__ ticket,
@@ -211,17 +212,17 @@ __global__ __launch_bounds__(256) void k_bin_count(DevTick k, const float4* __re
     }
     pt_slot[i] = slot;
   }
-  // ticket: every wave drains its atomics, then one device-scope add per workgroup
+  // Ticket.  The only data handed to the last workgroup are the cell counters, and
+  // those are touched exclusively by device-scope atomics (returned => performed)
+  // and read back with device-scope atomic loads, so no cache write-back /
+  // invalidate is needed: every wave drains its atomics, barrier, one relaxed
+  // device-scope add per workgroup.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (t == gridDim.x - 1) ? 1u : 0u;
     if (is_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       *ticket = 0;            // next tick
       *best_key = kKeyNone;
       *overflow = 0;
@@ -826,9 +827,16 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       }
       key = pack_key(cost, (uint32_t)gi);
     }
-    costs[li] = cost;
+    // cost + sample are read back by the last workgroup: device-scope (write-through)
+    // stores, matched by device-scope loads there -- no cache flush needed
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(costs) + li,
+                       (unsigned long long)__double_as_longlong(cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    float* so = reinterpret_cast<float*>(samples_out + li);
+    __hip_atomic_store(so + 0, h.vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(so + 1, h.vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(so + 2, h.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    so[3] = 0.f;
     steps_out[li] = h.steps;
-    samples_out[li] = make_float4(h.vx, h.vy, h.w, 0.f);
   }
   // wave-0 shuffle min-reduction of the packed keys, one atomic per workgroup
   if (tid < 64) {
@@ -840,19 +848,16 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     if (tid == 0 && key != kKeyNone) atomicMin((long long*)best_key, (long long)key);
   }
   // ---- winner decode by the last workgroup (local_planner.cpp:447-480) ----
-  // Placement-independent hand-off: drain stores, barrier, agent-scope release,
-  // device-scope ticket; the workgroup that draws the last ticket acquires and
-  // writes the result straight into host-mapped memory (no finalize launch, no
-  // D2H copy).
+  // Placement-independent hand-off: every byte handed over (key, cost, sample,
+  // capacity flag) is written with device-scope atomics / write-through stores and
+  // read with device-scope loads; waves drain their stores, barrier, one relaxed
+  // device-scope ticket.  The workgroup drawing the last ticket writes the result
+  // straight into host-mapped memory (no finalize launch, no D2H copy).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == gridDim.x - 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       *ticket = 0;
       DevResult r;
       r.key = __hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
