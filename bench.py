@@ -31,7 +31,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4"])
+    ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4", "C5"])
+    ap.add_argument("--backend", default=os.environ.get("DDDMR_BENCH_BACKEND", "nccl"),
+                    help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse ranks on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -52,33 +54,50 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the rollout engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    gpu = local_rank % torch.cuda.device_count()      # (several ranks may share a GPU only with --backend gloo)
+    torch.cuda.set_device(gpu)
+    dev = torch.device("cuda", gpu)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     # ---- workload ----
-    sc = scenes.bench_scene(args.workload)
+    base = "C2" if args.workload == "C5" else args.workload
+    sc = scenes.bench_scene(base)
     theory = sc.theory
     scaling = "weak"
-    if args.workload == "C2":
+    if base == "C2":
         theory.linear_x_sample = 16.0 * world          # 4096 samples per GPU
-    elif args.workload == "C4":
+    elif base == "C4":
         scaling = "strong"
     name = theory.name.decode()
-    b = configs.BENCH[args.workload]
+    b = configs.BENCH[base]
     n_steps_traj = b["steps"]
 
-    lp = LocalPlanner([theory], device=local_rank, max_points=len(sc.cloud), max_trajectories=1 << 20,
+    lp = LocalPlanner([theory], device=gpu, max_points=len(sc.cloud), max_trajectories=1 << 20,
                       rank=rank, world_size=world)
     lp.set_cloud(sc.cloud)            # inputs resident in HBM before the timed region
     lp.setPlan(sc.plan)
+    scans = None
+    if args.workload == "C5":
+        # perception feed fused with the tick: 10 simulated 16-ring LiDAR scans of the C2
+        # scene; every step = set_scan (crop + 0.1 m voxel-hash downsample on the GPU,
+        # H2D of the raw scan included) + one C2 tick on the resulting cloud
+        scans = [scenes.lidar_scan(sc.cloud, seed=100 + i) for i in range(10)]
+        t_bs, t_gb = (0.0, 0.0, 0.5, 0, 0, 0, 1), (0.0, 0.0, 0.0, 0, 0, 0, 1)
+    step_no = [0]
 
-    key_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    key_t = torch.zeros(1, dtype=torch.int64, device=red_dev)
 
     def step():
+        if scans is not None:
+            lp.set_scan(scans[step_no[0] % len(scans)], t_bs, t_gb, 10.0, 2.0)
+            step_no[0] += 1
         res = lp.tick(name, sc.tick)
         if world > 1:
             key_t.fill_(res.key)
@@ -103,7 +122,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        et = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         elapsed = float(et.item())
 
@@ -119,7 +138,11 @@ def main():
         # reference evaluates of (32 + 16 k) + 32 M + 32 N_local, k = radius-search
         # result sizes, counted by the oracle on the very same inputs.
         b0, e0 = sharding.shard_range(0, world, n_global)
-        o = oracle.tick(theory, sc.cloud, sc.plan, sc.tick, begin=b0, end=e0, n_threads=os.cpu_count() or 1)
+        ocloud = sc.cloud
+        if scans is not None:       # the cloud the last tick actually scored
+            g = lp.get_cloud()
+            ocloud = np.ascontiguousarray(g)
+        o = oracle.tick(theory, ocloud, sc.plan, sc.tick, begin=b0, end=e0, n_threads=os.cpu_count() or 1)
         r = o.result
         units = int(r.steps_total)                         # trajectory-steps per launch
         alg_bytes = 32 * int(r.steps_eval) + 16 * int(r.k_sum) + 32 * len(sc.plan) + 32 * n_local
@@ -138,12 +161,12 @@ def main():
                     "alg_bytes_per_launch": alg_bytes, "units_per_launch": units,
                     "bytes_per_unit": round(per_unit, 2), "kernel_ms": round(k_ms, 5),
                     "tick_device_ms": round(float(np.mean(dev_ms)), 5),
-                    "tick_alg_bytes": alg_bytes + 16 * len(sc.cloud)}
+                    "tick_alg_bytes": alg_bytes + 16 * len(ocloud)}
         # parity spot check of what was just timed
-        parity_ok = bool(world > 1 or (res.best_index == r.best_index and abs(res.vx - r.vx) <= 1e-4
+        parity_ok = bool(world > 1 or scans is not None or (res.best_index == r.best_index and abs(res.vx - r.vx) <= 1e-4
                                        and abs(res.vy - r.vy) <= 1e-4 and abs(res.wz - r.wz) <= 1e-4))
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and scans is None:
             # the oracle ("port"), 1 core like the reference's loops, bounded sample
             n_ticks, t_cpu = 0, 0.0
             while t_cpu < args.cpu_seconds:
@@ -165,7 +188,8 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 5), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {n_global} trajectories x {n_steps_traj} steps vs "
-                                   f"{len(sc.cloud)}-point cloud, {len(sc.plan)}-pose prune plan, shipped critic stack",
+                                   f"{len(ocloud)}-point cloud, {len(sc.plan)}-pose prune plan, shipped critic stack"
+                                   + (", 16x1800 LiDAR scan -> set_scan (voxel-hash feed) fused into every step" if scans is not None else ""),
                        "trajectories_per_gpu": n_local, "steps_per_trajectory": n_steps_traj,
                        "trajectory_steps_per_s": round(value * n_steps_traj, 1),
                        "parallelism": f"traj-shard x{world}" if world > 1 else "single",

@@ -325,6 +325,44 @@ __host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m
   return (b + 15) & ~(size_t)15;
 }
 
+// Two points per instruction: gfx950's packed FP32 ops (v_pk_add_f32 / v_pk_mul_f32)
+// do the same IEEE operations as the scalar form, two lanes-values at a time, and
+// with contraction off no multiply-add is fused -- so the results are bit-identical
+// to l2_simple / dot3 above at half the VALU issue cost.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 l2_simple2(f2 ax, f2 ay, f2 az, float bx, float by, float bz) {
+#pragma clang fp contract(off)
+  f2 d = ax - bx;
+  f2 r = d * d;
+  d = ay - by;
+  r = r + d * d;
+  d = az - bz;
+  r = r + d * d;
+  return r;
+}
+__device__ __forceinline__ f2 dot3_2(f2 dx, f2 dy, f2 dz, float a, float b, float c) {
+#pragma clang fp contract(off)
+  return (dx * a + dy * b) + dz * c;
+}
+// box (and radius) verdicts of two cloud points against one OBB record:
+// bit 0 / bit 1 = point a / b collides (collision_model.cpp:122-139)
+__device__ __forceinline__ int box_test2(const float* r, const float4 a, const float4 b, bool use_radius) {
+#pragma clang fp contract(off)
+  const f2 x = {a.x, b.x}, y = {a.y, b.y}, z = {a.z, b.z};
+  const f2 dx = x - r[0], dy = y - r[1], dz = z - r[2];
+  const f2 xv = __builtin_elementwise_abs(dot3_2(dx, dy, dz, r[3], r[4], r[5]));
+  const f2 yv = __builtin_elementwise_abs(dot3_2(dx, dy, dz, r[6], r[7], r[8]));
+  const f2 zv = __builtin_elementwise_abs(dot3_2(dx, dy, dz, r[9], r[10], r[11]));
+  bool h0 = xv.x <= r[12] && yv.x <= r[13] && zv.x <= r[14];
+  bool h1 = xv.y <= r[12] && yv.y <= r[13] && zv.y <= r[14];
+  if (use_radius) {
+    const f2 d2 = l2_simple2(x, y, z, r[15], r[16], r[17]);   // FLANN: point - query squared the same
+    h0 = h0 && d2.x < 1.0f;
+    h1 = h1 && d2.y < 1.0f;
+  }
+  return (h0 ? 1 : 0) | (h1 ? 2 : 0);
+}
+
 __device__ __forceinline__ bool box_test(const float* r, float x, float y, float z) {
   // collision_model.cpp:124-139, float arithmetic in source order
   const float dx = fsub(x, r[0]), dy = fsub(y, r[1]), dz = fsub(z, r[2]);
@@ -567,9 +605,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       int i = 0;
       for (; i + 4 <= k.m; i += 4) {
         const float4 p0 = plan[i], p1 = plan[i + 1], p2 = plan[i + 2], p3 = plan[i + 3];
-        const float d0 = l2_simple(p0.x, p0.y, p0.z, px, py, pz), d1 = l2_simple(p1.x, p1.y, p1.z, px, py, pz);
-        const float d2 = l2_simple(p2.x, p2.y, p2.z, px, py, pz), d3 = l2_simple(p3.x, p3.y, p3.z, px, py, pz);
-        best = fminf(fminf(best, fminf(d0, d1)), fminf(d2, d3));
+        const f2 da = l2_simple2(f2{p0.x, p1.x}, f2{p0.y, p1.y}, f2{p0.z, p1.z}, px, py, pz);
+        const f2 db = l2_simple2(f2{p2.x, p3.x}, f2{p2.y, p3.y}, f2{p2.z, p3.z}, px, py, pz);
+        best = fminf(fminf(best, fminf(da.x, da.y)), fminf(db.x, db.y));
       }
       for (; i < k.m; ++i) {
         const float4 pp = plan[i];
@@ -602,6 +640,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       float v[4][3];
       float mnx = 3.402823466e+38f, mny = mnx, mnz = mnx, mxx = -mnx, mxy = -mnx, mxz = -mnx;
       float ccx = 0.f, ccy = 0.f, ccz = 0.f;
+      float vmax2 = 0.f;   // farthest vertex from the pose: if < 1 the box lies inside the search ball
       auto world_vertex = [&](int vtx, float& wx, float& wy, float& wz) {
         const double cx = k.cub[3 * vtx + 0], cy = k.cub[3 * vtx + 1], cz = k.cub[3 * vtx + 2];
         wx = (float)(L[0] * cx + L[1] * cy + L[2] * cz + T[0]);
@@ -611,6 +650,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         mny = fminf(mny, wy); mxy = fmaxf(mxy, wy);
         mnz = fminf(mnz, wz); mxz = fmaxf(mxz, wz);
         ccx = fadd(ccx, wx); ccy = fadd(ccy, wy); ccz = fadd(ccz, wz);   // centre sum in vertex order
+        const float ux = wx - px, uy = wy - py, uz = wz - pz;
+        vmax2 = fmaxf(vmax2, ux * ux + uy * uy + uz * uz);
       };
 #pragma unroll
       for (int vtx = 0; vtx < 4; ++vtx) world_vertex(vtx, v[vtx][0], v[vtx][1], v[vtx][2]);
@@ -643,7 +684,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       if (cx0 > cx1 || cy0 > cy1) { cx0 = 1; cx1 = 0; cy0 = 1; cy1 = 0; }
       reinterpret_cast<int*>(r)[18] = (cx0 & 0xFFFF) | (cx1 << 16);
       reinterpret_cast<int*>(r)[19] = (cy0 & 0xFFFF) | (cy1 << 16);
-      reinterpret_cast<int*>(r)[20] = j;
+      // A point inside the (convex) box is no farther from the pose than the farthest
+      // vertex, so with all vertices well inside the 1 m ball the radius test is moot.
+      reinterpret_cast<int*>(r)[20] = j | (vmax2 < 0.99f ? 0x10000 : 0);
       if (need_mm) { r[21] = mnx; r[22] = mny; r[23] = mnz; r[24] = mxx; r[25] = mxy; r[26] = mxz; }
       if (cy1 - cy0 + 1 > kRows) atomicOr(overflow, 2u);   // host sizes the cells so this cannot happen
     }
@@ -736,7 +779,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         const uint32_t sl_len = seg_len[sg];
         const int q = (int)(sl_len & 0xFFFu);
         const float* rq = rec + (size_t)q * rec_words;
-        const int j = reinterpret_cast<const int*>(rq)[20];
+        const int jw = reinterpret_cast<const int*>(rq)[20];
+        const int j = jw & 0xFFFF;
+        const bool use_radius = (jw & 0x10000) == 0;
         const bool hb = !need_box || head[j].hit_box != 0;
         const bool hm = !need_mm || head[j].hit_mm != 0;
         if (hb && hm) continue;                     // trajectory already decided
@@ -751,14 +796,23 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
 #pragma unroll
         for (int u = 0; u < 18; ++u) r[u] = rq[u];
         bool fb = false, fm = false;
+        if (need_box) {
+          int hits = 0;
 #pragma unroll
-        for (int u = 0; u < kItem; ++u) {
-          // radiusSearch(pose, 1.0): FLANN keeps dist^2 < r^2
-          const bool in = (uint32_t)u < n && l2_simple(r[15], r[16], r[17], pt[u].x, pt[u].y, pt[u].z) < 1.0f;
-          if (need_box) fb |= in && box_test(r, pt[u].x, pt[u].y, pt[u].z);
-          if (need_mm)
+          for (int u = 0; u < kItem; u += 2) {
+            const int h2 = box_test2(r, pt[u], pt[u + 1], use_radius);
+            hits |= ((uint32_t)u < n ? (h2 & 1) : 0) | ((uint32_t)(u + 1) < n ? (h2 & 2) : 0);
+          }
+          fb = hits != 0;
+        }
+        if (need_mm) {
+#pragma unroll
+          for (int u = 0; u < kItem; ++u) {
+            // radiusSearch(pose, 1.0): FLANN keeps dist^2 < r^2
+            const bool in = (uint32_t)u < n && l2_simple(r[15], r[16], r[17], pt[u].x, pt[u].y, pt[u].z) < 1.0f;
             fm |= in && (pt[u].x >= rq[21] && pt[u].x <= rq[24] && pt[u].y >= rq[22] && pt[u].y <= rq[25] &&
                          pt[u].z >= rq[23] && pt[u].z <= rq[26]);
+          }
         }
         if (fb) atomicOr(&head[j].hit_box, 1);
         if (fm) atomicOr(&head[j].hit_mm, 1);

@@ -20,17 +20,19 @@ with LocalPlanner([sc.theory], max_points=len(sc.cloud)) as lp:
     lib.dddmr_rollout_diag_stamps.argtypes = [C.c_void_p, C.c_size_t]
     assert lib.dddmr_rollout_diag_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
     st = buf.reshape(n_wg, SL)
-    used = st[:, 7] > 0
-    st = st[used].astype(np.int64)
+    st = st.astype(np.int64)
+    newest = st[:, 7].max()
+    used = (st[:, 7] > 0) & (newest - st[:, 0] < 3_000_000)   # stamps of the last launch only
+    st = st[used]
     print(cfg, "workgroups", len(st), "score_ms", r.score_ms)
     names = ["A theta", "B trig+index", "C xy", "D1 pose/path/obb", "D2 segments+scan", "D3 walk", "E score"]
     t0 = st[:, 0].min()
     for i, nm in enumerate(names):
-        d = (st[:, i + 1] - st[:, i]) / 100.0   # s_memtime ticks at 100 MHz -> us
-        print(f"  {nm:18s} mean {d.mean():8.2f} us  p50 {np.percentile(d,50):8.2f}  p99 {np.percentile(d,99):8.2f}  max {d.max():8.2f}")
-    life = (st[:, 7] - st[:, 0]) / 100.0
-    print(f"  workgroup lifetime mean {life.mean():.2f} us max {life.max():.2f} us; first start -> last end {(st[:,7].max()-t0)/100.0:.2f} us")
-    start = (st[:, 0] - t0) / 100.0
+        d = (st[:, i + 1] - st[:, i]) / 1000.0   # kilo-cycles (s_memtime counts shader clocks)
+        print(f"  {nm:18s} mean {d.mean():8.2f} kc  p50 {np.percentile(d,50):8.2f}  p99 {np.percentile(d,99):8.2f}  max {d.max():8.2f}")
+    life = (st[:, 7] - st[:, 0]) / 1000.0
+    print(f"  workgroup lifetime mean {life.mean():.2f} us max {life.max():.2f} us; first start -> last end {(st[:,7].max()-t0)/1000.0:.2f} us")
+    start = (st[:, 0] - t0) / 1000.0
     print(f"  start times: p50 {np.percentile(start,50):.2f} p90 {np.percentile(start,90):.2f} max {start.max():.2f} us")
     tot = st[:, 9]
     print(f"  items per wg: mean {tot.mean():.0f} max {tot.max()}  corr(items, D3 time) {np.corrcoef(tot, st[:,6]-st[:,5])[0,1]:.3f}")
