@@ -92,20 +92,34 @@ def main():
         t_bs, t_gb = (0.0, 0.0, 0.5, 0, 0, 0, 1), (0.0, 0.0, 0.0, 0, 0, 0, 1)
     step_no = [0]
 
-    key_t = torch.zeros(1, dtype=torch.int64, device=red_dev)
+    # Multi-rank: the 8-byte min all-reduce of tick i is issued asynchronously and
+    # collected while tick i+1 computes (the winner of a tick is delivered one tick
+    # later; every all-reduce completes inside the timed region).
+    key_bufs = [torch.zeros(1, dtype=torch.int64, device=red_dev) for _ in range(2)]
+    pending = []          # [(work handle, buffer)]
+    resolved = [None]
+
+    def collect():
+        while pending:
+            work, buf = pending.pop(0)
+            work.wait()
+            resolved[0] = lp.resolve(int(buf.item()))
 
     def step():
         if scans is not None:
             lp.set_scan(scans[step_no[0] % len(scans)], t_bs, t_gb, 10.0, 2.0)
-            step_no[0] += 1
         res = lp.tick(name, sc.tick)
         if world > 1:
-            key_t.fill_(res.key)
-            dist.all_reduce(key_t, op=dist.ReduceOp.MIN)     # RCCL over xGMI, 8 bytes
-            res = lp.resolve(int(key_t.item()))
+            buf = key_bufs[step_no[0] % 2]
+            collect()                                        # all-reduce of the previous tick
+            buf.fill_(res.key)
+            pending.append((dist.all_reduce(buf, op=dist.ReduceOp.MIN, async_op=True), buf))   # RCCL over xGMI, 8 bytes
+            res = resolved[0] if resolved[0] is not None else res
+        step_no[0] += 1
         return res
 
     def fence():
+        collect()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -121,6 +135,8 @@ def main():
         score_ms.append(lp.last_result.score_ms)
     fence()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        res = resolved[0]
     if world > 1:
         et = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)

@@ -200,6 +200,7 @@ struct dddmr_rollout_ctx {
   Window last_window;
   float cell_size = 0.25f;
   int tile_override = 0;
+  int timing = 1;   // DDDMR_TIMING: 0 no HIP events, 1 around k_score (score_ms), 2 also around the whole tick
 };
 
 namespace {
@@ -358,6 +359,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     if (v > 0.01f && v < 10.f) ctx->cell_size = v;
   }
   if (const char* e = std::getenv("DDDMR_TILE")) ctx->tile_override = std::atoi(e);
+  if (const char* e = std::getenv("DDDMR_TIMING")) ctx->timing = std::atoi(e);
 
   auto init = [&]() -> int {
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -705,7 +707,7 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   }
   if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
 
-  HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->timing >= 2) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const int bin_blocks = std::max(1, std::min(2048, (k.n_points + 255) / 256));
   const int cnt_blocks = std::max(1, std::min(512, (k.n_points + kBinThreads - 1) / kBinThreads));
   if (k.n_points > 0) {
@@ -717,7 +719,7 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
     hipLaunchKernelGGL(k_bin_reset, dim3(1), dim3(256), 0, ctx->stream, k, ctx->cell_count, ctx->cell_start,
                        ctx->best_key, ctx->overflow);
   }
-  HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
+  if (ctx->timing >= 1) HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
   if (k.n_local > 0) {
     const int wgs = (k.n_local + tile - 1) / tile;
     hipLaunchKernelGGL(k_score, dim3(wgs), dim3(kScoreThreads), lds, ctx->stream, k, ctx->axes_dev,
@@ -726,14 +728,14 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   } else {
     hipLaunchKernelGGL(k_empty_result, dim3(1), dim3(64), 0, ctx->stream, k, ctx->cell_start, ctx->result_dev);
   }
-  HIPCHK(ctx, hipEventRecord(ctx->evs1, ctx->stream));
-  HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  if (ctx->timing >= 1) HIPCHK(ctx, hipEventRecord(ctx->evs1, ctx->stream));
+  if (ctx->timing >= 2) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   HIPCHK(ctx, hipGetLastError());
   float ms = 0.f;
-  HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  if (ctx->timing >= 2) HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   float score_ms = 0.f;
-  HIPCHK(ctx, hipEventElapsedTime(&score_ms, ctx->evs0, ctx->evs1));
+  if (ctx->timing >= 1) HIPCHK(ctx, hipEventElapsedTime(&score_ms, ctx->evs0, ctx->evs1));
 
   const DevResult r = *ctx->result_host;
   ctx->last = k;
@@ -783,14 +785,10 @@ int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key, dddmr_rol
   inout->planner_state = DDDMR_TRAJECTORY_FOUND;
   inout->best_index = idx;
   inout->vx = vx; inout->vy = vy; inout->wz = wz;
-  const int li = idx - ctx->last.begin;
-  if (li >= 0 && li < ctx->last.n_local) {
-    HIPCHK(ctx, hipSetDevice(ctx->device));
-    double c = 0;
-    HIPCHK(ctx, hipMemcpy(&c, ctx->costs + li, sizeof(double), hipMemcpyDeviceToHost));
-    inout->best_cost = c;
+  if (ctx->result_host->index == idx) {
+    inout->best_cost = ctx->result_host->cost;   // this rank's own winner: exact
   } else {
-    // winner lives on another rank: the key carries the cost's top 40 bits
+    // winner lives on another rank (or an older tick): the key carries the cost's top 40 bits
     union { double d; uint64_t u; } cv;
     cv.u = (uint64_t)reduced_key & ~((1ull << kKeyIndexBits) - 1);
     inout->best_cost = cv.d;
