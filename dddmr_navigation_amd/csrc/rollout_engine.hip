@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
@@ -201,6 +202,10 @@ struct dddmr_rollout_ctx {
   float cell_size = 0.25f;
   int tile_override = 0;
   int timing = 1;   // DDDMR_TIMING: 0 no HIP events, 1 around k_score (score_ms), 2 also around the whole tick
+  int timing_every = 1;   // DDDMR_TIMING_EVERY: record the events on every n-th tick only
+  int spin = 1;     // DDDMR_SPIN: poll the host-mapped result instead of hipStreamSynchronize
+  uint32_t seq = 0;
+  float last_score_ms = 0.f, last_device_ms = 0.f;
 };
 
 namespace {
@@ -360,6 +365,8 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
   }
   if (const char* e = std::getenv("DDDMR_TILE")) ctx->tile_override = std::atoi(e);
   if (const char* e = std::getenv("DDDMR_TIMING")) ctx->timing = std::atoi(e);
+  if (const char* e = std::getenv("DDDMR_TIMING_EVERY")) ctx->timing_every = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("DDDMR_SPIN")) ctx->spin = std::atoi(e);
 
   auto init = [&]() -> int {
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -707,7 +714,12 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   }
   if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
 
-  if (ctx->timing >= 2) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  k.seq = ++ctx->seq;
+  if (k.seq == 0) k.seq = ctx->seq = 1;
+  // HIP events serialise the queue around them (~3 us each); timed ticks are sampled
+  const bool timed = ctx->timing >= 1 && (ctx->seq % (uint32_t)ctx->timing_every) == 0;
+  const bool timed_all = timed && ctx->timing >= 2;
+  if (timed_all) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const int bin_blocks = std::max(1, std::min(2048, (k.n_points + 255) / 256));
   const int cnt_blocks = std::max(1, std::min(512, (k.n_points + kBinThreads - 1) / kBinThreads));
   if (k.n_points > 0) {
@@ -719,7 +731,7 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
     hipLaunchKernelGGL(k_bin_reset, dim3(1), dim3(256), 0, ctx->stream, k, ctx->cell_count, ctx->cell_start,
                        ctx->best_key, ctx->overflow);
   }
-  if (ctx->timing >= 1) HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
+  if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
   if (k.n_local > 0) {
     const int wgs = (k.n_local + tile - 1) / tile;
     hipLaunchKernelGGL(k_score, dim3(wgs), dim3(kScoreThreads), lds, ctx->stream, k, ctx->axes_dev,
@@ -728,14 +740,30 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   } else {
     hipLaunchKernelGGL(k_empty_result, dim3(1), dim3(64), 0, ctx->stream, k, ctx->cell_start, ctx->result_dev);
   }
-  if (ctx->timing >= 1) HIPCHK(ctx, hipEventRecord(ctx->evs1, ctx->stream));
-  if (ctx->timing >= 2) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs1, ctx->stream));
+  if (timed_all) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(ctx, hipGetLastError());
-  float ms = 0.f;
-  if (ctx->timing >= 2) HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-  float score_ms = 0.f;
-  if (ctx->timing >= 1) HIPCHK(ctx, hipEventElapsedTime(&score_ms, ctx->evs0, ctx->evs1));
+  // The last k_score workgroup stores the result into host-mapped memory and then
+  // the tick's sequence number (system-scope release): polling it beats a stream
+  // synchronise by several microseconds.  Bounded; falls back to the stream sync.
+  bool seen = false;
+  if (ctx->spin) {
+    volatile uint32_t* seq_p = &ctx->result_host->seq;
+    for (uint64_t spins = 0; spins < (1ull << 26); ++spins) {
+      if (*seq_p == k.seq) { seen = true; break; }
+#if defined(__x86_64__)
+      __builtin_ia32_pause();
+#endif
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+  }
+  if (!seen) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  if (timed) {
+    HIPCHK(ctx, hipEventSynchronize(timed_all ? ctx->ev1 : ctx->evs1));
+    if (timed_all) HIPCHK(ctx, hipEventElapsedTime(&ctx->last_device_ms, ctx->ev0, ctx->ev1));
+    HIPCHK(ctx, hipEventElapsedTime(&ctx->last_score_ms, ctx->evs0, ctx->evs1));
+  }
+  const float ms = ctx->last_device_ms, score_ms = ctx->last_score_ms;   // latest sampled values
 
   const DevResult r = *ctx->result_host;
   ctx->last = k;
@@ -801,6 +829,7 @@ int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg) {
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
   if (!ctx->have_last) return fail(ctx, DDDMR_ERR_STATE, "get_debug before any tick");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the tick may have returned on the polled sequence number
   const size_t n = (size_t)ctx->last.n_local;
   if (n == 0) return DDDMR_OK;
   if (dbg->costs) HIPCHK(ctx, hipMemcpy(dbg->costs, ctx->costs, n * sizeof(double), hipMemcpyDeviceToHost));
@@ -822,6 +851,7 @@ int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out, size
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
   if (!ctx->have_last) return fail(ctx, DDDMR_ERR_STATE, "get_best_poses before any tick");
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   const int32_t idx = ctx->result_host->index;
   *n_poses = 0;
   if (idx < 0) return DDDMR_OK;

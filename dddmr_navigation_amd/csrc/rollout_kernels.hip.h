@@ -78,6 +78,7 @@ struct DevTick {
   // sample axes inline in the kernarg segment when they fit (no per-tick H2D copy):
   // x at [0,nx), y at [nx,nx+ny), theta at [nx+ny, nx+ny+nth)
   int axes_inline;
+  uint32_t seq;      // tick sequence number echoed into DevResult::seq
   float axes_inl[kInlineAxes];
 };
 
@@ -88,6 +89,8 @@ struct DevResult {    // written by the last k_score workgroup into host-mapped 
   int32_t index;      // global sample index or -1
   uint32_t n_binned;
   uint32_t overflow;  // 1 if a trajectory needed more than max_steps
+  uint32_t seq;       // tick sequence number, stored LAST: the host may poll it instead of a stream sync
+  uint32_t pad;
 };
 
 __host__ __device__ inline int64_t pack_key(double cost, uint32_t gidx) {
@@ -930,8 +933,11 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       }
       r.n_binned = cell_start[k.n_cells];
       r.overflow = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      r.seq = 0;
+      r.pad = 0;
       *result = r;
       __threadfence_system();
+      __hip_atomic_store(&result->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   DDDMR_STAMP(7);
@@ -948,8 +954,11 @@ __global__ void k_empty_result(DevTick k, const uint32_t* __restrict__ cell_star
   r.vx = r.vy = r.wz = 0.f;
   r.n_binned = cell_start[k.n_cells];
   r.overflow = 0;
+  r.seq = 0;
+  r.pad = 0;
   *res = r;
   __threadfence_system();
+  __hip_atomic_store(&res->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // Poses of one trajectory for visualisation (local_planner.cpp:472-478 publishes

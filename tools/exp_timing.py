@@ -6,6 +6,8 @@ from dddmr_navigation_amd.local_planner import LocalPlanner
 
 def run(cfg, cloud_mode="full", iters=50):
     sc = scenes.bench_scene(cfg)
+    if os.environ.get('EXP_NX'):
+        sc.theory.linear_x_sample = float(os.environ['EXP_NX'])
     cloud = sc.cloud
     if cloud_mode == "empty":
         cloud = cloud[:0]
