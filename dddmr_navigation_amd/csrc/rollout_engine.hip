@@ -172,6 +172,10 @@ struct dddmr_rollout_ctx {
   uint32_t* overflow = nullptr;
   DevResult* result_dev = nullptr;   // device alias of result_host (host-mapped)
   uint32_t* tickets = nullptr;       // [0] binning ticket, [1] scoring ticket
+  OrderState* order = nullptr;       // launch-order feedback (device)
+  uint32_t* perm[2] = {nullptr, nullptr};
+  int order_tiles = -1, order_theory = -1, order_nlocal = -1;
+  uint32_t order_seq = 0;
   double* poses_dev = nullptr;
   // perception feed scratch
   PerceptionScratch feed{};
@@ -321,7 +325,7 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   }
   void* dev[] = {ctx->pt_slot, ctx->sorted, ctx->cell_count, ctx->cell_start, ctx->axes_dev,
                  ctx->samples_dev, ctx->plan_dev, ctx->costs, ctx->steps, ctx->samples_out,
-                 ctx->best_key, ctx->overflow, ctx->tickets, ctx->poses_dev};
+                 ctx->best_key, ctx->overflow, ctx->tickets, ctx->poses_dev, ctx->order, ctx->perm[0], ctx->perm[1]};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   perception_free(ctx->feed);
@@ -396,6 +400,10 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMalloc(&ctx->samples_out, N * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&ctx->best_key, sizeof(int64_t)));
     HIPCHK(ctx, hipMalloc(&ctx->overflow, sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->order, sizeof(OrderState)));
+    HIPCHK(ctx, hipMemset(ctx->order, 0, sizeof(OrderState)));
+    HIPCHK(ctx, hipMalloc(&ctx->perm[0], N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->perm[1], N * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->tickets, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(ctx->tickets, 0, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->poses_dev, (size_t)cfg->max_steps * 7 * sizeof(double)));
@@ -734,9 +742,19 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
   if (k.n_local > 0) {
     const int wgs = (k.n_local + tile - 1) / tile;
+    // Launch-order feedback only carries over between ticks of the same launch shape
+    // (and consecutive sequence numbers: the books are double-buffered by parity).
+    const int theory_id = (int)(th - ctx->theories.data());
+    const bool same = ctx->order_tiles == wgs && ctx->order_theory == theory_id && ctx->order_nlocal == k.n_local &&
+                      ctx->order_seq + 1 == k.seq;
+    if (!same) HIPCHK(ctx, hipMemsetAsync(ctx->order, 0, sizeof(OrderState), ctx->stream));
+    k.use_perm = (wgs > 256 && !std::getenv("DDDMR_NO_PERM")) ? 1 : 0;
+    if (k.use_perm && std::getenv("DDDMR_PERM_IDENT")) k.use_perm = 2;   // experiment: keep the books, launch in index order
+    ctx->order_tiles = wgs; ctx->order_theory = theory_id; ctx->order_nlocal = k.n_local; ctx->order_seq = k.seq;
     hipLaunchKernelGGL(k_score, dim3(wgs), dim3(kScoreThreads), lds, ctx->stream, k, ctx->axes_dev,
                        ctx->samples_dev, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
-                       ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev);
+                       ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev,
+                       ctx->order, ctx->perm[0], ctx->perm[1]);
   } else {
     hipLaunchKernelGGL(k_empty_result, dim3(1), dim3(64), 0, ctx->stream, k, ctx->cell_start, ctx->result_dev);
   }

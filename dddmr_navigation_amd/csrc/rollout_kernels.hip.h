@@ -78,8 +78,33 @@ struct DevTick {
   // sample axes inline in the kernarg segment when they fit (no per-tick H2D copy):
   // x at [0,nx), y at [nx,nx+ny), theta at [nx+ny, nx+ny+nth)
   int axes_inline;
+  int use_perm;      // launch-order feedback is valid for this launch shape
   uint32_t seq;      // tick sequence number echoed into DevResult::seq
   float axes_inl[kInlineAxes];
+};
+
+// Launch-order feedback (device resident, double-buffered by tick parity): every
+// k_score workgroup files its tile under a load class; the next tick dispatches
+// the heaviest classes first so that the long workgroups start at once and the
+// tail of the launch is made of light ones.  Any order gives identical results.
+constexpr int kLoadClasses = 8;
+struct alignas(128) OrderBook {        // atomically updated while a launch runs: one 128-B line per counter kind
+  uint32_t cnt[kLoadClasses];          // tiles filed per class
+  uint32_t pad0[32 - kLoadClasses];
+  uint32_t sum;                        // total load (collision work items)
+  uint32_t pad1[31];
+  uint32_t bad;                        // a class region overflowed => perm is not a permutation
+  uint32_t pad2[31];
+};
+struct alignas(128) OrderPlan {        // read-only while a launch runs (written by the previous launch's last workgroup)
+  uint32_t base[kLoadClasses + 1];     // class regions of perm[]
+  uint32_t mean;                       // load per tile
+  uint32_t valid;
+  uint32_t pad[32 - kLoadClasses - 3];
+};
+struct OrderState {
+  OrderBook book[2];
+  OrderPlan plan[2];
 };
 
 struct DevResult {    // written by the last k_score workgroup into host-mapped memory
@@ -380,7 +405,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
     const float4* __restrict__ sorted, double* __restrict__ costs, int32_t* __restrict__ steps_out,
     float4* __restrict__ samples_out, int64_t* __restrict__ best_key, uint32_t* __restrict__ overflow,
-    uint32_t* __restrict__ ticket, DevResult* __restrict__ result) {
+    uint32_t* __restrict__ ticket, DevResult* __restrict__ result, OrderState* __restrict__ order,
+    uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tile = k.tile;
   const int S1 = k.max_steps + 1;
@@ -424,7 +450,12 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   // space) or expensive (along a wall); striding mixes them so that the
   // workgroups carry similar amounts of collision work.
   const int n_tiles = gridDim.x;
-  const int nt = (k.n_local - (int)blockIdx.x + n_tiles - 1) / n_tiles;   // <= tile
+  const int par = (int)(k.seq & 1u), prv = par ^ 1;
+  uint32_t* perm_cur = par ? perm1 : perm0;        // filled by this tick
+  const uint32_t* perm_prv = par ? perm0 : perm1;  // filled by the previous tick
+  // tile taken by this workgroup: heaviest-first order measured by the previous tick
+  const int tb = (k.use_perm == 1 && order->plan[prv].valid) ? (int)perm_prv[blockIdx.x] : (int)blockIdx.x;
+  const int nt = (k.n_local - tb + n_tiles - 1) / n_tiles;   // <= tile
 
   DDDMR_STAMP(0);
   // ---- stage the prune plan (float xyz, model_shared_data.h:83-91) ----
@@ -432,7 +463,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
 
   // ---- phase A: sample, generation gates, step count, theta recurrence ----
   if (tid < nt) {
-    const int li = (int)blockIdx.x + tid * n_tiles;
+    const int li = tb + tid * n_tiles;
     const int gi = k.begin + li;
     float vx, vy, w;
     if (k.list_mode) {
@@ -697,6 +728,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   __syncthreads();
 
   DDDMR_STAMP(4);   // end of phase D1
+  uint32_t wg_items = 0;   // collision work items of this tile = its load for the launch-order feedback
   if (do_coll && total_pairs > 0) {
     // ---- phase D2: row segments per pair -----------------------------------
     // z is the fastest cell axis, then x: the cells [cx0..cx1] x all z of one y-row
@@ -759,6 +791,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     }
     const int nseg = (int)(carry >> 32);
     const uint32_t total = (uint32_t)carry;
+    wg_items = total;
     if (tid == 0) pref[nseg] = total;
     __syncthreads();
 
@@ -829,7 +862,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   int64_t key = kKeyNone;
   if (tid < nt) {
     const TrajHead h = head[tid];
-    const int li = (int)blockIdx.x + tid * n_tiles;
+    const int li = tb + tid * n_tiles;
     const int gi = k.begin + li;
     double cost = DDDMR_COST_NOT_GENERATED;
     if (h.steps > 0) {
@@ -910,12 +943,42 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   // read with device-scope loads; waves drain their stores, barrier, one relaxed
   // device-scope ticket.  The workgroup drawing the last ticket writes the result
   // straight into host-mapped memory (no finalize launch, no D2H copy).
+  if (tid == 0 && k.use_perm) {
+    // file this tile under its load class (regions sized by the previous tick's histogram)
+    const uint32_t mean = __hip_atomic_load(&order->plan[prv].mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int c = kLoadClasses - 1;
+    if (mean > 0) {
+      const float x = (float)wg_items / (float)mean;
+      c = x >= 3.0f ? 0 : x >= 2.5f ? 1 : x >= 2.0f ? 2 : x >= 1.6f ? 3 : x >= 1.3f ? 4 : x >= 1.0f ? 5 : x >= 0.5f ? 6 : 7;
+    }
+    const uint32_t pos = __hip_atomic_fetch_add(&order->book[par].cnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t b0 = order->plan[prv].base[c], b1 = order->plan[prv].base[c + 1];
+    if (b0 + pos < b1) __hip_atomic_store(&perm_cur[b0 + pos], (uint32_t)tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else __hip_atomic_store(&order->book[par].bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&order->book[par].sum, wg_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == gridDim.x - 1) {
       *ticket = 0;
+      if (k.use_perm) {
+        // close this tick's order book: valid iff every class filled exactly its region
+        uint32_t acc = 0, ok = __hip_atomic_load(&order->book[par].bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+        for (int c = 0; c < kLoadClasses; ++c) {
+          const uint32_t n = __hip_atomic_load(&order->book[par].cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = ok && (n == order->plan[prv].base[c + 1] - order->plan[prv].base[c]);
+          order->plan[par].base[c] = acc;
+          acc += n;
+          order->book[prv].cnt[c] = 0;                 // the next tick files into the other parity
+        }
+        order->plan[par].base[kLoadClasses] = acc;
+        order->plan[par].valid = ok ? 1u : 0u;
+        order->plan[par].mean = __hip_atomic_load(&order->book[par].sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (uint32_t)n_tiles;
+        order->book[prv].sum = 0;
+        order->book[prv].bad = 0;
+      }
       DevResult r;
       r.key = __hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       r.index = key_index(r.key);
