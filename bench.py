@@ -110,13 +110,16 @@ def main():
     def step():
         if scans is not None:
             lp.set_scan(scans[step_no[0] % len(scans)], t_bs, t_gb, 10.0, 2.0)
-        res = lp.tick(name, sc.tick)
         if world > 1:
+            lp.tick_begin(name, sc.tick)                     # GPU computes tick i ...
+            collect()                                        # ... while the host finishes tick i-1's all-reduce
+            res = lp.tick_end()
             buf = key_bufs[step_no[0] % 2]
-            collect()                                        # all-reduce of the previous tick
             buf.fill_(res.key)
             pending.append((dist.all_reduce(buf, op=dist.ReduceOp.MIN, async_op=True), buf))   # RCCL over xGMI, 8 bytes
             res = resolved[0] if resolved[0] is not None else res
+        else:
+            res = lp.tick(name, sc.tick)
         step_no[0] += 1
         return res
 

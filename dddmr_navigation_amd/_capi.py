@@ -152,6 +152,8 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_get_cloud",
     "dddmr_rollout_set_prune_plan",
     "dddmr_rollout_tick",
+    "dddmr_rollout_tick_begin",
+    "dddmr_rollout_tick_end",
     "dddmr_rollout_resolve",
     "dddmr_rollout_get_debug",
     "dddmr_rollout_get_best_poses",
@@ -200,6 +202,10 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_set_prune_plan.restype = C.c_int
     lib.dddmr_rollout_tick.argtypes = [ctx_p, C.c_char_p, C.POINTER(TickInput), C.POINTER(RolloutResult)]
     lib.dddmr_rollout_tick.restype = C.c_int
+    lib.dddmr_rollout_tick_begin.argtypes = [ctx_p, C.c_char_p, C.POINTER(TickInput)]
+    lib.dddmr_rollout_tick_begin.restype = C.c_int
+    lib.dddmr_rollout_tick_end.argtypes = [ctx_p, C.POINTER(RolloutResult)]
+    lib.dddmr_rollout_tick_end.restype = C.c_int
     lib.dddmr_rollout_resolve.argtypes = [ctx_p, C.c_int64, C.POINTER(RolloutResult)]
     lib.dddmr_rollout_resolve.restype = C.c_int
     lib.dddmr_rollout_get_debug.argtypes = [ctx_p, C.POINTER(RolloutDebug)]

@@ -209,7 +209,17 @@ struct dddmr_rollout_ctx {
   int timing_every = 1;   // DDDMR_TIMING_EVERY: record the events on every n-th tick only
   int spin = 1;     // DDDMR_SPIN: poll the host-mapped result instead of hipStreamSynchronize
   uint32_t seq = 0;
+  DevResult last_result{};   // host copy of the last COLLECTED tick's result
   float last_score_ms = 0.f, last_device_ms = 0.f;
+  // a tick whose kernels are enqueued but whose result has not been collected yet
+  struct Pending {
+    bool active = false;
+    DevTick k{};
+    int s_tick = 0;
+    bool timed = false, timed_all = false;
+    dddmr_rollout_result head{};   // n_samples / shard fields known at enqueue time
+    Window window;                 // becomes last_window when the tick is collected
+  } pend;
 };
 
 namespace {
@@ -533,6 +543,7 @@ int dddmr_rollout_set_prune_plan(dddmr_rollout_ctx* ctx, const double* poses, si
     return fail(ctx, DDDMR_ERR_CAPACITY, "set_prune_plan: %zu poses > max_plan_poses %u", n_poses,
                 ctx->cfg.max_plan_poses);
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "set_prune_plan while a tick_begin is pending");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   // ModelSharedData::updateData: positions as float PointXYZI (model_shared_data.h:83-91)
   std::vector<float4> xyz(std::max<size_t>(n_poses, 1));
@@ -546,10 +557,19 @@ int dddmr_rollout_set_prune_plan(dddmr_rollout_ctx* ctx, const double* poses, si
   return DDDMR_OK;
 }
 
-int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_tick_input* in,
-                       dddmr_rollout_result* out) {
-  if (!ctx || !theory_name || !in || !out) return DDDMR_ERR_BAD_ARG;
-  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+}  // extern "C"
+
+namespace {
+
+void release_cloud(dddmr_rollout_ctx* c) {
+  { std::lock_guard<std::mutex> lk(c->cloud_mu); c->busy = -1; }
+  c->cloud_cv.notify_all();
+}
+
+// Enqueue one tick (host-side initialise() + 3 launches); tick_mu must be held.
+int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_tick_input* in) {
+  dddmr_rollout_result head_storage;
+  dddmr_rollout_result* out = &head_storage;
   std::memset(out, 0, sizeof(*out));
   out->planner_state = DDDMR_ALL_TRAJECTORIES_FAIL;
   out->best_index = -1;
@@ -560,7 +580,7 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   HIPCHK(ctx, hipSetDevice(ctx->device));
 
   // ---- initialise(): velocity samples of this tick ----
-  Window& w = ctx->last_window;
+  Window& w = ctx->pend.window;
   make_window(*th, *in, w);
   const size_t N = w.count();
   if (N > ctx->cfg.max_trajectories)
@@ -654,12 +674,10 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
     pending = ctx->front_pending;
     ctx->front_pending = false;
   }
-  struct Unbusy {
+  struct Unbusy {          // releases the cloud buffer again if enqueueing fails half-way
     dddmr_rollout_ctx* c;
-    ~Unbusy() {
-      { std::lock_guard<std::mutex> lk(c->cloud_mu); c->busy = -1; }
-      c->cloud_cv.notify_all();
-    }
+    bool armed = true;
+    ~Unbusy() { if (armed) release_cloud(c); }
   } unbusy{ctx};
   k.n_points = (int)ctx->cloud_n[cidx];
   tile_extent(*th, w, k.R, k.t, sim_time_eff, k.rmin, k.rmax);
@@ -761,6 +779,23 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs1, ctx->stream));
   if (timed_all) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(ctx, hipGetLastError());
+  unbusy.armed = false;   // the cloud buffer stays pinned until tick_collect
+  ctx->pend.active = true;
+  ctx->pend.k = k;
+  ctx->pend.s_tick = s_tick;
+  ctx->pend.timed = timed;
+  ctx->pend.timed_all = timed_all;
+  ctx->pend.head = *out;
+  return DDDMR_OK;
+}
+
+// Wait for the enqueued tick and decode its result; tick_mu must be held.
+int tick_collect(dddmr_rollout_ctx* ctx, dddmr_rollout_result* out) {
+  if (!ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "tick_end without tick_begin");
+  ctx->pend.active = false;
+  struct Release { dddmr_rollout_ctx* c; ~Release() { release_cloud(c); } } release{ctx};
+  const DevTick& k = ctx->pend.k;
+  *out = ctx->pend.head;
   // The last k_score workgroup stores the result into host-mapped memory and then
   // the tick's sequence number (system-scope release): polling it beats a stream
   // synchronise by several microseconds.  Bounded; falls back to the stream sync.
@@ -776,19 +811,21 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
     std::atomic_thread_fence(std::memory_order_acquire);
   }
   if (!seen) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  if (timed) {
-    HIPCHK(ctx, hipEventSynchronize(timed_all ? ctx->ev1 : ctx->evs1));
-    if (timed_all) HIPCHK(ctx, hipEventElapsedTime(&ctx->last_device_ms, ctx->ev0, ctx->ev1));
+  if (ctx->pend.timed) {
+    HIPCHK(ctx, hipEventSynchronize(ctx->pend.timed_all ? ctx->ev1 : ctx->evs1));
+    if (ctx->pend.timed_all) HIPCHK(ctx, hipEventElapsedTime(&ctx->last_device_ms, ctx->ev0, ctx->ev1));
     HIPCHK(ctx, hipEventElapsedTime(&ctx->last_score_ms, ctx->evs0, ctx->evs1));
   }
   const float ms = ctx->last_device_ms, score_ms = ctx->last_score_ms;   // latest sampled values
 
   const DevResult r = *ctx->result_host;
+  ctx->last_result = r;
   ctx->last = k;
+  ctx->last_window = ctx->pend.window;
   ctx->have_last = true;
   if (r.overflow)
     return fail(ctx, DDDMR_ERR_CAPACITY, "device capacity flag %u (1: trajectory longer than %d steps, 2: cuboid spans more than %d cell rows)",
-                r.overflow, s_tick, kRows);
+                r.overflow, ctx->pend.s_tick, kRows);
   out->device_ms = ms;
   out->score_ms = score_ms;
   out->n_points_binned = r.n_binned;
@@ -800,6 +837,38 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dd
     out->vx = r.vx; out->vy = r.vy; out->wz = r.wz;
   }
   return DDDMR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_tick_input* in,
+                       dddmr_rollout_result* out) {
+  if (!ctx || !theory_name || !in || !out) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "tick while a tick_begin is pending");
+  std::memset(out, 0, sizeof(*out));
+  out->planner_state = DDDMR_ALL_TRAJECTORIES_FAIL;
+  out->best_index = -1;
+  out->best_cost = -1.0;
+  out->key = kKeyNone;
+  const int rc = tick_enqueue(ctx, theory_name, in);
+  if (rc != DDDMR_OK) return rc;
+  return tick_collect(ctx, out);
+}
+
+int dddmr_rollout_tick_begin(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_tick_input* in) {
+  if (!ctx || !theory_name || !in) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "tick_begin while another tick_begin is pending");
+  return tick_enqueue(ctx, theory_name, in);
+}
+
+int dddmr_rollout_tick_end(dddmr_rollout_ctx* ctx, dddmr_rollout_result* out) {
+  if (!ctx || !out) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  return tick_collect(ctx, out);
 }
 
 int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key, dddmr_rollout_result* inout) {
@@ -831,8 +900,8 @@ int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key, dddmr_rol
   inout->planner_state = DDDMR_TRAJECTORY_FOUND;
   inout->best_index = idx;
   inout->vx = vx; inout->vy = vy; inout->wz = wz;
-  if (ctx->result_host->index == idx) {
-    inout->best_cost = ctx->result_host->cost;   // this rank's own winner: exact
+  if (ctx->last_result.index == idx) {
+    inout->best_cost = ctx->last_result.cost;   // this rank's own winner: exact
   } else {
     // winner lives on another rank (or an older tick): the key carries the cost's top 40 bits
     union { double d; uint64_t u; } cv;
@@ -846,6 +915,7 @@ int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg) {
   if (!ctx || !dbg) return DDDMR_ERR_BAD_ARG;
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
   if (!ctx->have_last) return fail(ctx, DDDMR_ERR_STATE, "get_debug before any tick");
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "get_debug while a tick_begin is pending");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // the tick may have returned on the polled sequence number
   const size_t n = (size_t)ctx->last.n_local;
@@ -870,7 +940,8 @@ int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out, size
   if (!ctx->have_last) return fail(ctx, DDDMR_ERR_STATE, "get_best_poses before any tick");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  const int32_t idx = ctx->result_host->index;
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "get_best_poses while a tick_begin is pending");
+  const int32_t idx = ctx->last_result.index;
   *n_poses = 0;
   if (idx < 0) return DDDMR_OK;
   const int li = idx - ctx->last.begin;

@@ -147,6 +147,16 @@ class LocalPlanner:
         self.last_result = res
         return res
 
+    def tick_begin(self, traj_gen_name: str, tick_in: K.TickInput) -> None:
+        """Enqueue a tick and return at once (pair with tick_end)."""
+        self._check(self._lib.dddmr_rollout_tick_begin(self._ctx, traj_gen_name.encode(), C.byref(tick_in)))
+
+    def tick_end(self) -> K.RolloutResult:
+        res = K.RolloutResult()
+        self._check(self._lib.dddmr_rollout_tick_end(self._ctx, C.byref(res)))
+        self.last_result = res
+        return res
+
     def computeVelocityCommand(self, traj_gen_name: str, best_traj: Trajectory, tick_in: K.TickInput) -> PlannerState:
         """Local_Planner::computeVelocityCommand (local_planner.cpp:482-621), the
         section :535-587; fills best_traj like the reference does."""

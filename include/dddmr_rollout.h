@@ -238,6 +238,16 @@ int dddmr_rollout_set_prune_plan(dddmr_rollout_ctx* ctx, const double* poses_xyz
 int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name,
                        const dddmr_tick_input* in, dddmr_rollout_result* out);
 
+/* Split form of dddmr_rollout_tick for hosts that want to overlap their own work
+   (e.g. the previous tick's all-reduce) with the GPU: tick_begin enqueues the
+   tick and returns at once, tick_end waits for it and fills the result.  Exactly
+   one tick may be pending per context; set_prune_plan / tick / get_* return
+   DDDMR_ERR_STATE while one is.  set_cloud / set_scan stay allowed (they fill the
+   back buffer).  dddmr_rollout_tick == tick_begin + tick_end. */
+int dddmr_rollout_tick_begin(dddmr_rollout_ctx* ctx, const char* theory_name,
+                             const dddmr_tick_input* in);
+int dddmr_rollout_tick_end(dddmr_rollout_ctx* ctx, dddmr_rollout_result* out);
+
 /* Multi-rank hosts: after every rank's tick, min-reduce result.key over the
    ranks (one 8-byte all-reduce) and resolve the winner on every rank. */
 int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key,

@@ -249,6 +249,27 @@ def test_host_mirror_compute_velocity_command_and_poses():
         np.testing.assert_allclose(poses, ref, atol=1e-5)
 
 
+def test_tick_begin_end_equals_tick_and_guards_state():
+    sc = scenes.bench_scene("C1")
+    name = sc.theory.name.decode()
+    with LocalPlanner([sc.theory]) as lp:
+        lp.set_cloud(sc.cloud)
+        lp.setPlan(sc.plan)
+        ref = lp.tick(name, sc.tick)
+        lp.tick_begin(name, sc.tick)
+        for call in (lambda: lp.tick(name, sc.tick), lambda: lp.tick_begin(name, sc.tick), lambda: lp.setPlan(sc.plan)):
+            with pytest.raises(RolloutError) as e:
+                call()
+            assert e.value.code == K.ERR_STATE
+        lp.set_cloud(sc.cloud)                      # the sensor thread may still feed the back buffer
+        res = lp.tick_end()
+        assert (res.key, res.best_index, res.vx, res.wz, res.best_cost) == (ref.key, ref.best_index, ref.vx, ref.wz, ref.best_cost)
+        with pytest.raises(RolloutError) as e:
+            lp.tick_end()
+        assert e.value.code == K.ERR_STATE
+        assert lp.tick(name, sc.tick).key == ref.key
+
+
 # ---- sharding on one GPU: every rank's context, then the 8-byte min -----------
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_contexts_agree_with_unsharded(world):
