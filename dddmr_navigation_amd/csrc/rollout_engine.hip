@@ -701,6 +701,8 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   }
   k.inv_cell = 1.0f / cell;
   for (int i = 0; i < 3; ++i) k.gmin[i] = k.rmin[i];
+  // rows <= floor(span / cell) + 2 (span = cuboid diameter clipped to the 2 m search ball)
+  k.rows_cap = std::min(kRows, (int)std::floor(std::min(diam, 2.0) * 1.001 / cell) + 2);
 
   // trajectories per workgroup: ~one (trajectory, step) pair per lane
   // ~160 pairs per 256-thread workgroup measured best on MI355X (C2: tile 3, C3: tile 2):
@@ -712,8 +714,8 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     const long te = (long)(k.gnx + 1) * k.gny;
     k.tab_entries = (te <= kTabCap && k.n_points >= 5 && (k.want_collision || k.want_minmax)) ? (int)te : 0;
   }
-  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0, k.tab_entries) > 72 * 1024) --tile;
-  const size_t lds = score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0, k.tab_entries);
+  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0, k.tab_entries, k.rows_cap) > 72 * 1024) --tile;
+  const size_t lds = score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0, k.tab_entries, k.rows_cap);
   if (lds > (size_t)kScoreLdsMax) return fail(ctx, DDDMR_ERR_CAPACITY, "horizon needs %zu bytes of LDS", lds);
   k.tile = tile;
 

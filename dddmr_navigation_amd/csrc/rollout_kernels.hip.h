@@ -79,6 +79,7 @@ struct DevTick {
   // x at [0,nx), y at [nx,nx+ny), theta at [nx+ny, nx+ny+nth)
   int axes_inline;
   int use_perm;      // launch-order feedback is valid for this launch shape
+  int rows_cap;      // cell rows one cuboid AABB can span with this tick's cell size (<= kRows)
   uint32_t seq;      // tick sequence number echoed into DevResult::seq
   float axes_inl[kInlineAxes];
 };
@@ -324,6 +325,7 @@ struct TrajHead {     // per-trajectory header in LDS
   int pad;
   double pp_dist;     // PurePursuitModel: |translation| of the pose difference
   double pp_yaw;      // PurePursuitModel: folded yaw of the pose difference
+  double stick_sum;   // StickPathModel: sum of the per-step 1-NN distances
 };
 
 constexpr int kRecWords = 21;       // odd stride: conflict-free field reads across lanes
@@ -333,7 +335,8 @@ constexpr int kItem = 8;            // points per work item of the collision wal
 constexpr int kTabCap = 4096;       // (gnx+1)*gny row-run boundaries staged in LDS when they fit
 
 // dynamic LDS carve, see k_score (rows are max_steps+1 long):
-__host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m, bool omni, bool want_mm, int tab_entries) {
+__host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m, bool omni, bool want_mm, int tab_entries,
+                                                  int rows_cap) {
   const size_t S1 = (size_t)max_steps + 1;
   const size_t Q = (size_t)tile * (size_t)max_steps;
   size_t b = 0;
@@ -346,8 +349,8 @@ __host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m
   b += 8 * (size_t)tile * S1;                        // xy
   b += 4 * (size_t)tile * S1;                        // dist
   b += 4 * (size_t)(want_mm ? kRecWordsMM : kRecWords) * Q;   // OBB records
-  b += 4 * (Q * kRows + 1);                          // item prefix sums per (pair,row) slot
-  b += 8 * (Q * kRows);                              // segment start + length per slot
+  b += 4 * (Q * (size_t)rows_cap + 1);               // item prefix sums per non-empty (pair,row) segment
+  b += 8 * (Q * (size_t)rows_cap);                   // segment start + length
   b += 4 * (size_t)tab_entries;                      // costmap row-run index (cell_start slice), 0 = not staged
   b += 64;                                           // scan scratch
   return (b + 15) & ~(size_t)15;
@@ -433,11 +436,11 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   float* rec = reinterpret_cast<float*>(lds_raw + ofs);
   ofs += 4 * (size_t)rec_words * Qcap;
   uint32_t* pref = reinterpret_cast<uint32_t*>(lds_raw + ofs);
-  ofs += 4 * ((size_t)Qcap * kRows + 1);
+  ofs += 4 * ((size_t)Qcap * k.rows_cap + 1);
   uint32_t* seg_p = reinterpret_cast<uint32_t*>(lds_raw + ofs);
-  ofs += 4 * (size_t)Qcap * kRows;
+  ofs += 4 * (size_t)Qcap * k.rows_cap;
   uint32_t* seg_len = reinterpret_cast<uint32_t*>(lds_raw + ofs);
-  ofs += 4 * (size_t)Qcap * kRows;
+  ofs += 4 * (size_t)Qcap * k.rows_cap;
   uint32_t* tab = reinterpret_cast<uint32_t*>(lds_raw + ofs);
   ofs += 4 * (size_t)k.tab_entries;
   ofs = (ofs + 7) & ~(size_t)7;
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     h.dt = dt;
     h.pair_base = 0;
     h.hit_box = 0; h.hit_mm = 0; h.pad = 0;
-    h.pp_dist = 0.0; h.pp_yaw = 0.0;
+    h.pp_dist = 0.0; h.pp_yaw = 0.0; h.stick_sum = 0.0;
     head[tid] = h;
     // theta_{k+1} = float(theta_k + w*dt)   (computeNewPositions, :457-464)
     float* row = th + (size_t)tid * S1;
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       // vertex, so with all vertices well inside the 1 m ball the radius test is moot.
       reinterpret_cast<int*>(r)[20] = j | (vmax2 < 0.99f ? 0x10000 : 0);
       if (need_mm) { r[21] = mnx; r[22] = mny; r[23] = mnz; r[24] = mxx; r[25] = mxy; r[26] = mxz; }
-      if (cy1 - cy0 + 1 > kRows) atomicOr(overflow, 2u);   // host sizes the cells so this cannot happen
+      if (cy1 - cy0 + 1 > k.rows_cap) atomicOr(overflow, 2u);   // host sizes the cells so this cannot happen
     }
   }
   __syncthreads();
@@ -736,34 +739,42 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     // Slot q*kRows + r holds row r of pair q.  Work is cut into ITEMS of up to
     // kItem consecutive points of one segment so that every lane of the walk
     // executes the same unrolled body.
-    const int nslots = total_pairs * kRows;
-    // One packed 64-bit exclusive scan gives, per (pair,row) slot, both the index
-    // of the slot among the NON-EMPTY ones (high word) and the number of items in
-    // front of it (low word); empty slots (open space: most of them) are dropped so
-    // the walk never has to step over them.
+    // One lane per pair looks its (<= kRows) cell rows up; ONE packed 64-bit
+    // exclusive scan over the pairs gives both the index of a pair's first NON-EMPTY
+    // segment (high word) and the number of items in front of it (low word); each
+    // lane then writes its own segments.  Empty rows (open space: most of them) are
+    // dropped so the walk never has to step over them.
     unsigned long long carry = 0;
-    for (int base = 0; base < nslots; base += kScoreThreads) {
-      const int sl = base + tid;
-      uint32_t b = 0, len = 0;
-      int q = 0;
-      if (sl < nslots) {
-        q = sl / kRows;
-        const int rr = sl - q * kRows;
+    for (int base = 0; base < total_pairs; base += kScoreThreads) {
+      const int q = base + tid;
+      uint32_t rb[kRows], rl[kRows];
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) { rb[r] = 0; rl[r] = 0; }
+      unsigned long long cnt = 0;
+      if (q < total_pairs) {
         const int* ri = reinterpret_cast<const int*>(rec + (size_t)q * rec_words);
         const int cx0 = (short)(ri[18] & 0xFFFF), cx1 = ri[18] >> 16;
         const int cy0 = (short)(ri[19] & 0xFFFF), cy1 = ri[19] >> 16;
-        const int cy = cy0 + rr;
-        if (cx0 <= cx1 && cy <= cy1) {
-          if (tab_staged) {
-            b = tab[cy * (k.gnx + 1) + cx0];
-            len = tab[cy * (k.gnx + 1) + cx1 + 1] - b;
-          } else {
-            b = cell_start[(cy * k.gnx + cx0) * k.gnz];
-            len = cell_start[(cy * k.gnx + cx1 + 1) * k.gnz] - b;
+        if (cx0 <= cx1) {
+#pragma unroll
+          for (int r = 0; r < kRows; ++r) {
+            const int cy = cy0 + r;
+            if (cy <= cy1) {
+              uint32_t b, e;
+              if (tab_staged) {
+                b = tab[cy * (k.gnx + 1) + cx0];
+                e = tab[cy * (k.gnx + 1) + cx1 + 1];
+              } else {
+                b = cell_start[(cy * k.gnx + cx0) * k.gnz];
+                e = cell_start[(cy * k.gnx + cx1 + 1) * k.gnz];
+              }
+              rb[r] = b;
+              rl[r] = e - b;
+              if (e > b) cnt += (1ull << 32) | (unsigned long long)((e - b + kItem - 1) / kItem);
+            }
           }
         }
       }
-      const unsigned long long cnt = len ? ((1ull << 32) | (unsigned long long)((len + kItem - 1) / kItem)) : 0ull;
       unsigned long long incl = cnt;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
@@ -779,12 +790,19 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         if (wv < wid) wofs += v;
         tot += v;
       }
-      if (len) {
+      if (cnt) {
         const unsigned long long ex = carry + wofs + incl - cnt;
-        const uint32_t ci = (uint32_t)(ex >> 32);
-        pref[ci] = (uint32_t)ex;
-        seg_p[ci] = b;
-        seg_len[ci] = (len << 12) | (uint32_t)q;     // pair index < 4096, run length < 2^20
+        uint32_t ci = (uint32_t)(ex >> 32), itn = (uint32_t)ex;
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+          if (rl[r]) {
+            pref[ci] = itn;
+            seg_p[ci] = rb[r];
+            seg_len[ci] = (rl[r] << 12) | (uint32_t)q;     // pair index < 4096, run length < 2^20
+            ++ci;
+            itn += (rl[r] + kItem - 1) / kItem;
+          }
+        }
       }
       carry += tot;
       __syncthreads();
@@ -858,6 +876,20 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   __syncthreads();
 
   DDDMR_STAMP(6);   // end of phase D3
+  // StickPath's sum of per-step distances (stick_path_model.cpp:62-73): one wave per
+  // trajectory, lanes stride the steps, fixed xor-shuffle tree in double (the
+  // reference adds in step order; the difference is <= 1e-15 relative).
+  for (int j = wid; j < nt; j += kScoreThreads / 64) {
+    const int ns = head[j].steps;
+    const float* dr = dist + (size_t)j * S1;
+    double acc = 0.0;
+    for (int s2 = lane; s2 < ns; s2 += 64) acc += (double)dr[s2];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) head[j].stick_sum = acc;
+  }
+  __syncthreads();
+
   // ---- phase E: stacked scoring (stacked_scoring_model.cpp:75-93) + argmin ----
   int64_t key = kKeyNone;
   if (tid < nt) {
@@ -881,15 +913,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
             if (k.m < 3) {
               r = 10.0;
             } else {
-              double acc = 0.0;      // summed in step order like the reference's loop
-              int s = 0;
-              for (; s + 8 <= h.steps; s += 8) {
-                const float d0 = dr[s], d1 = dr[s + 1], d2 = dr[s + 2], d3 = dr[s + 3];
-                const float d4 = dr[s + 4], d5 = dr[s + 5], d6 = dr[s + 6], d7 = dr[s + 7];
-                acc += (double)d0; acc += (double)d1; acc += (double)d2; acc += (double)d3;
-                acc += (double)d4; acc += (double)d5; acc += (double)d6; acc += (double)d7;
-              }
-              for (; s < h.steps; ++s) acc += (double)dr[s];
+              const double acc = h.stick_sum;
               r = acc / (double)k.m;
             }
             break;

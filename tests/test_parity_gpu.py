@@ -330,6 +330,32 @@ def test_full_size_properties_c3():
     assert 0.05 < (c1 == -1.0).mean() < 0.98
 
 
+def test_c4_batch_65536_sharded_over_8_contexts():
+    """BASELINE config 4: 65536 trajectories x 50 steps; 8 shard contexts (one GPU
+    here) + the 8-byte min == the unsharded tick, and the winner obeys the
+    reference's last-wins scan over the concatenated costs."""
+    sc = scenes.bench_scene("C4")
+    name = sc.theory.name.decode()
+    res0, costs0, steps0, _ = gpu_tick(sc.theory, sc.cloud, sc.plan, sc.tick, max_trajectories=1 << 17)
+    assert res0.n_samples == 65536 and (steps0 == 50).all()
+    keys, parts = [], []
+    for r in range(8):
+        with LocalPlanner([sc.theory], max_points=len(sc.cloud), max_trajectories=1 << 17, rank=r, world_size=8) as lp:
+            lp.set_cloud(sc.cloud)
+            lp.setPlan(sc.plan)
+            res = lp.tick(name, sc.tick)
+            assert (res.local_begin, res.n_local) == (8192 * r, 8192)
+            keys.append(res.key)
+            parts.append(lp.debug()[0])
+    allc = np.concatenate(parts)
+    np.testing.assert_array_equal(allc, costs0)
+    assert min(keys) == res0.key
+    ok = allc >= 0
+    m = allc[ok].min()
+    assert res0.best_index == int(np.nonzero(allc == m)[0][-1])       # last of the equal minima
+    assert sharding.key_index(min(keys)) == res0.best_index
+
+
 def test_set_cloud_from_sensor_thread_while_ticking():
     sc = scenes.bench_scene("C1")
     name = sc.theory.name.decode()
