@@ -1,0 +1,103 @@
+"""Randomised differential test: random robot poses (full SE(3)), cuboids (incl.
+boxes larger than the 1 m search ball), limits, theories, critic stacks, plans and
+clouds -- HIP path vs oracle, same bar as tests/test_parity_gpu.py."""
+import math
+
+import numpy as np
+import pytest
+
+from dddmr_navigation_amd import _capi as K, configs, scenes
+from dddmr_navigation_amd.local_planner import LocalPlanner
+import oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def random_case(rng):
+    kind = rng.choice(["dd", "omni", "rot"], p=[0.45, 0.4, 0.15])
+    # cuboid: random box (sometimes long: corners beyond the 1 m ball), reference vertex order
+    lx0, lx1 = -rng.uniform(0.1, 0.9), rng.uniform(0.2, 1.3 if rng.random() < 0.3 else 0.7)
+    ly = rng.uniform(0.15, 0.6)
+    lz0, lz1 = rng.uniform(-0.1, 0.1), rng.uniform(0.3, 1.2)
+    named = {"flb": (lx1, ly, lz0), "frb": (lx1, -ly, lz0), "flt": (lx1, ly, lz1), "frt": (lx1, -ly, lz1),
+             "blb": (lx0, ly, lz0), "brb": (lx0, -ly, lz0), "blt": (lx0, ly, lz1), "brt": (lx0, -ly, lz1)}
+    cub = configs.cuboid_vertices(named)
+    stack = [configs.critic(K.CRITIC_COLLISION if rng.random() < 0.8 else K.CRITIC_COLLISION_MIN_MAX)]
+    if rng.random() < 0.2:
+        stack.append(configs.critic(K.CRITIC_COLLISION_MIN_MAX))
+    pool = [configs.critic(K.CRITIC_STICK_PATH), configs.critic(K.CRITIC_TOWARD_GLOBAL_PLAN, weight=rng.uniform(0.2, 2)),
+            configs.critic(K.CRITIC_PURE_PURSUIT, translation_weight=rng.uniform(0.2, 2), orientation_weight=rng.uniform(0, 0.5)),
+            configs.critic(K.CRITIC_TWIRLING, weight=rng.uniform(0, 1)), configs.critic(K.CRITIC_SHORTEST_ANGLE, weight=rng.uniform(0.5, 2))]
+    for i in rng.permutation(len(pool))[: rng.integers(0, 5)]:
+        stack.append(pool[i])
+    sim_time = float(rng.uniform(1.0, 4.0))
+    common = dict(sim_time=sim_time, sim_granularity=float(rng.choice([0.05, 0.1])),
+                  angular_sim_granularity=float(rng.choice([0.025, 0.05])), critics=stack, cuboid=cub)
+    if kind == "dd":
+        th = configs.dd_simple_shipped(name="t", linear_x_sample=float(rng.integers(2, 9)),
+                                       angular_z_sample=float(rng.integers(2, 14)), max_vel_x=float(rng.uniform(0.5, 1.5)),
+                                       max_vel_theta=float(rng.uniform(0.3, 1.0)), **common)
+        twist = (rng.uniform(0.0, 1.0), 0.0, rng.uniform(-0.3, 0.3))
+    elif kind == "omni":
+        th = configs.omni_simple_shipped(name="t", linear_x_sample=float(rng.integers(2, 6)),
+                                         linear_y_sample=float(rng.integers(2, 6)), angular_z_sample=float(rng.integers(2, 9)), **common)
+        twist = (rng.uniform(-0.5, 0.8), rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3))
+    else:
+        common.pop("sim_time")
+        th = configs.rotate_inplace_shipped("t", rotation_speed=float(rng.uniform(0.2, 0.8)), **common)
+        twist = (0.0, 0.0, 0.0)
+    # pose: anywhere, any attitude (ramps up to ~20 deg)
+    q = scenes.quat_from_rpy(rng.uniform(-0.35, 0.35), rng.uniform(-0.35, 0.35), rng.uniform(-math.pi, math.pi))
+    pos = rng.uniform(-30, 30, 3) * np.array([1, 1, 0.1])
+    tick = scenes.tick_input(pose=tuple(pos) + q, twist=twist, allowed_max=(-1.0 if rng.random() < 0.7 else rng.uniform(0.2, 1.0)),
+                             heading_deviation=rng.uniform(-1, 1))
+    # cloud: clutter around the robot (global frame), a few walls, sometimes tiny
+    n = int(rng.choice([0, 3, 5, 200, 3000, 20000]))
+    pts = rng.uniform(-5, 5, (n, 3)) * np.array([1, 1, 0.3]) + pos
+    if n >= 200:
+        wall = np.stack([np.full(400, pos[0] + rng.uniform(0.6, 2.5)), pos[1] + rng.uniform(-3, 3, 400),
+                         pos[2] + rng.uniform(-0.5, 1.5, 400)], axis=1)
+        pts = np.concatenate([pts, wall])
+    cloud = np.zeros((len(pts), 4), dtype=np.float32)
+    cloud[:, :3] = pts
+    # plan: a curve starting near the robot
+    m = int(rng.choice([0, 2, 3, 20, 120]))
+    plan = np.zeros((m, 7))
+    yaw0 = rng.uniform(-math.pi, math.pi)
+    for i in range(m):
+        s = 0.05 * i
+        plan[i, 0] = pos[0] + s * math.cos(yaw0) + 0.2 * math.sin(s)
+        plan[i, 1] = pos[1] + s * math.sin(yaw0)
+        plan[i, 2] = pos[2] + 0.02 * s
+        plan[i, 3:7] = scenes.quat_from_rpy(0.0, 0.02, yaw0 + 0.3 * math.sin(s))
+    return th, cloud, plan, tick
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_scenario(seed):
+    rng = np.random.default_rng(1000 + seed)
+    th, cloud, plan, tick = random_case(rng)
+    with LocalPlanner([th], max_points=max(len(cloud), 16), max_steps=512) as lp:
+        lp.set_cloud(cloud)
+        lp.setPlan(plan)
+        res = lp.tick("t", tick)
+        costs, steps, smp = lp.debug()
+    o = oracle.tick(th, cloud, plan, tick, n_threads=8, want_margin=True)
+    np.testing.assert_array_equal(steps, o.steps)
+    np.testing.assert_array_equal(smp, o.samples)
+    fragile = np.abs(o.min_margin) < TOL
+    neg = (costs < 0) | (o.costs < 0)
+    bad = neg & (costs != o.costs) & ~fragile
+    assert not bad.any(), (np.nonzero(bad)[0][:5], costs[bad][:5], o.costs[bad][:5], o.min_margin[bad][:5])
+    both = (costs >= 0) & (o.costs >= 0)
+    if both.any():
+        assert np.max(np.abs(costs[both] - o.costs[both])) <= TOL
+    if not (neg & (costs != o.costs)).any():
+        # near-ties below the float noise floor may legitimately pick either sample
+        r = o.result
+        assert res.planner_state == r.planner_state
+        if res.best_index != r.best_index:
+            assert abs(costs[res.best_index] - o.costs[r.best_index]) <= 1e-6
+        else:
+            assert abs(res.vx - r.vx) <= TOL and abs(res.vy - r.vy) <= TOL and abs(res.wz - r.wz) <= TOL
