@@ -394,6 +394,13 @@ __device__ __forceinline__ int box_test2(const float* r, const float4 a, const f
   return (h0 ? 1 : 0) | (h1 ? 2 : 0);
 }
 
+// translation of trans_gbl2traj = pos_af3 * [Rz(theta), (x, y, 0)] (one definition so
+// that every phase rounds it identically)
+__device__ __forceinline__ void pose_translation(const DevTick& k, float2 bxy, double T[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) T[i] = k.R[3 * i + 0] * (double)bxy.x + k.R[3 * i + 1] * (double)bxy.y + k.t[i];
+}
+
 __device__ __forceinline__ bool box_test(const float* r, float x, float y, float z) {
   // collision_model.cpp:124-139, float arithmetic in source order
   const float dx = fsub(x, r[0]), dy = fsub(y, r[1]), dz = fsub(z, r[2]);
@@ -446,6 +453,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   ofs = (ofs + 7) & ~(size_t)7;
   unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(lds_raw + ofs);
 
+  __shared__ int alive_pairs_s;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   // Tile b scores local trajectories b, b + n_tiles, b + 2 n_tiles, ...: neighbours
@@ -632,26 +640,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       L[3 * i + 0] = r0 * c + r1 * sn;
       L[3 * i + 1] = r1 * c - r0 * sn;
       L[3 * i + 2] = r2;
-      T[i] = r0 * (double)bxy.x + r1 * (double)bxy.y + k.t[i];
     }
+    pose_translation(k, bxy, T);
     const float px = (float)T[0], py = (float)T[1], pz = (float)T[2];   // trajectory.cpp:69-75
-
-    // ---- path critics: exact 1-NN distance to the prune plan ----
-    {
-      float best = 3.402823466e+38f;
-      int i = 0;
-      for (; i + 4 <= k.m; i += 4) {
-        const float4 p0 = plan[i], p1 = plan[i + 1], p2 = plan[i + 2], p3 = plan[i + 3];
-        const f2 da = l2_simple2(f2{p0.x, p1.x}, f2{p0.y, p1.y}, f2{p0.z, p1.z}, px, py, pz);
-        const f2 db = l2_simple2(f2{p2.x, p3.x}, f2{p2.y, p3.y}, f2{p2.z, p3.z}, px, py, pz);
-        best = fminf(fminf(best, fminf(da.x, da.y)), fminf(db.x, db.y));
-      }
-      for (; i < k.m; ++i) {
-        const float4 pp = plan[i];
-        best = fminf(best, l2_simple(pp.x, pp.y, pp.z, px, py, pz));
-      }
-      dist[(size_t)j * S1 + s] = sqrtf(best);
-    }
 
     // ---- pure pursuit on the last pose (pure_pursuit_model.cpp:86-113) ----
     if (s == head[j].steps - 1) {
@@ -731,7 +722,19 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   __syncthreads();
 
   DDDMR_STAMP(4);   // end of phase D1
-  uint32_t wg_items = 0;   // collision work items of this tile = its load for the launch-order feedback
+  uint32_t ob_pos = 0;     // this tile's slot inside its load class (launch-order feedback)
+  int ob_cls = kLoadClasses - 1;
+  auto file_order = [&](uint32_t items) {
+    // file this tile under its load class (regions sized by the previous tick's histogram);
+    // issued as early as the load is known so the atomics' latency hides behind later phases
+    const uint32_t mean = __hip_atomic_load(&order->plan[prv].mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (mean > 0) {
+      const float x = (float)items / (float)mean;
+      ob_cls = x >= 3.0f ? 0 : x >= 2.5f ? 1 : x >= 2.0f ? 2 : x >= 1.6f ? 3 : x >= 1.3f ? 4 : x >= 1.0f ? 5 : x >= 0.5f ? 6 : 7;
+    }
+    ob_pos = __hip_atomic_fetch_add(&order->book[par].cnt[ob_cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_add(&order->book[par].sum, items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
   if (do_coll && total_pairs > 0) {
     // ---- phase D2: row segments per pair -----------------------------------
     // z is the fastest cell axis, then x: the cells [cx0..cx1] x all z of one y-row
@@ -809,8 +812,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     }
     const int nseg = (int)(carry >> 32);
     const uint32_t total = (uint32_t)carry;
-    wg_items = total;
     if (tid == 0) pref[nseg] = total;
+    if (tid == 0 && k.use_perm) file_order(total);
     __syncthreads();
 
     DDDMR_STAMP(5);   // end of phase D2
@@ -876,6 +879,52 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   __syncthreads();
 
   DDDMR_STAMP(6);   // end of phase D3
+  if (tid == 0 && k.use_perm && !(do_coll && total_pairs > 0)) file_order(0u);
+  // ---- phase P: path critics, only for trajectories that did not collide ----
+  // A collision verdict makes the trajectory's cost -1 whatever the path critics
+  // would return (first negative return wins and StickPath / TowardGlobalPlan never
+  // return a negative value when the plan has >= 3 poses), exactly like the
+  // reference never reaches them after CollisionModel returned -1
+  // (stacked_scoring_model.cpp:83-86).  With most samples colliding in cluttered
+  // scenes this skips most of the 1-NN searches.
+  if (tid == 0) {
+    int acc = 0;
+    for (int j = 0; j < nt; ++j) {
+      const bool dead = cloud_ok && ((need_box && head[j].hit_box) || (need_mm && head[j].hit_mm));
+      head[j].pad = acc;                                  // first surviving pair of trajectory j
+      acc += dead ? 0 : head[j].steps;
+    }
+    alive_pairs_s = acc;
+  }
+  __syncthreads();
+  for (int q2 = tid; q2 < alive_pairs_s; q2 += kScoreThreads) {
+    int j = 0;
+    while (j + 1 < nt && head[j + 1].pad <= q2) ++j;      // (dead trajectories have empty ranges)
+    const int s = q2 - head[j].pad;
+    const float2 bxy = xy[(size_t)j * S1 + s];
+    double T[3];
+    pose_translation(k, bxy, T);
+    const float px = (float)T[0], py = (float)T[1], pz = (float)T[2];
+    // exact 1-NN distance to the prune plan (FLANN float distance)
+    {
+      float best = 3.402823466e+38f;
+      int i = 0;
+      for (; i + 4 <= k.m; i += 4) {
+        const float4 p0 = plan[i], p1 = plan[i + 1], p2 = plan[i + 2], p3 = plan[i + 3];
+        const f2 da = l2_simple2(f2{p0.x, p1.x}, f2{p0.y, p1.y}, f2{p0.z, p1.z}, px, py, pz);
+        const f2 db = l2_simple2(f2{p2.x, p3.x}, f2{p2.y, p3.y}, f2{p2.z, p3.z}, px, py, pz);
+        best = fminf(fminf(best, fminf(da.x, da.y)), fminf(db.x, db.y));
+      }
+      for (; i < k.m; ++i) {
+        const float4 pp = plan[i];
+        best = fminf(best, l2_simple(pp.x, pp.y, pp.z, px, py, pz));
+      }
+      dist[(size_t)j * S1 + s] = sqrtf(best);
+    }
+
+  }
+  __syncthreads();
+
   // StickPath's sum of per-step distances (stick_path_model.cpp:62-73): one wave per
   // trajectory, lanes stride the steps, fixed xor-shuffle tree in double (the
   // reference adds in step order; the difference is <= 1e-15 relative).
@@ -968,18 +1017,10 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   // device-scope ticket.  The workgroup drawing the last ticket writes the result
   // straight into host-mapped memory (no finalize launch, no D2H copy).
   if (tid == 0 && k.use_perm) {
-    // file this tile under its load class (regions sized by the previous tick's histogram)
-    const uint32_t mean = __hip_atomic_load(&order->plan[prv].mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int c = kLoadClasses - 1;
-    if (mean > 0) {
-      const float x = (float)wg_items / (float)mean;
-      c = x >= 3.0f ? 0 : x >= 2.5f ? 1 : x >= 2.0f ? 2 : x >= 1.6f ? 3 : x >= 1.3f ? 4 : x >= 1.0f ? 5 : x >= 0.5f ? 6 : 7;
-    }
-    const uint32_t pos = __hip_atomic_fetch_add(&order->book[par].cnt[c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t b0 = order->plan[prv].base[c], b1 = order->plan[prv].base[c + 1];
-    if (b0 + pos < b1) __hip_atomic_store(&perm_cur[b0 + pos], (uint32_t)tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // the order-book slot was drawn right after D2 (its latency hid behind the walk)
+    const uint32_t b0 = order->plan[prv].base[ob_cls], b1 = order->plan[prv].base[ob_cls + 1];
+    if (b0 + ob_pos < b1) __hip_atomic_store(&perm_cur[b0 + ob_pos], (uint32_t)tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else __hip_atomic_store(&order->book[par].bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&order->book[par].sum, wg_items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();

@@ -8,8 +8,11 @@ from dddmr_navigation_amd.local_planner import LocalPlanner
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "C2"
 sc = scenes.bench_scene(cfg)
+import os
+if os.environ.get("EXP_EMPTY"):
+    sc.cloud = sc.cloud[:0]
 lib = K.load_library()
-with LocalPlanner([sc.theory], max_points=len(sc.cloud)) as lp:
+with LocalPlanner([sc.theory], max_points=max(len(sc.cloud), 16)) as lp:
     lp.set_cloud(sc.cloud); lp.setPlan(sc.plan)
     name = sc.theory.name.decode()
     for _ in range(5):
@@ -21,8 +24,9 @@ with LocalPlanner([sc.theory], max_points=len(sc.cloud)) as lp:
     assert lib.dddmr_rollout_diag_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
     st = buf.reshape(n_wg, SL)
     st = st.astype(np.int64)
-    newest = st[:, 7].max()
-    used = (st[:, 7] > 0) & (newest - st[:, 0] < 3_000_000)   # stamps of the last launch only
+    nwg = int(os.environ.get('EXP_NWG', '1366'))
+    used = np.zeros(len(st), bool); used[:nwg] = True
+    used &= st[:, 7] > 0
     st = st[used]
     print(cfg, "workgroups", len(st), "score_ms", r.score_ms)
     names = ["A theta", "B trig+index", "C xy", "D1 pose/path/obb", "D2 segments+scan", "D3 walk", "E score"]
@@ -33,6 +37,10 @@ with LocalPlanner([sc.theory], max_points=len(sc.cloud)) as lp:
     life = (st[:, 7] - st[:, 0]) / 1000.0
     print(f"  workgroup lifetime mean {life.mean():.2f} us max {life.max():.2f} us; first start -> last end {(st[:,7].max()-t0)/1000.0:.2f} us")
     start = (st[:, 0] - t0) / 1000.0
+    end = (st[:, 7] - t0) / 1000.0
+    order = np.argsort(start)
+    print("  start-time deciles (kc):", np.round(np.percentile(start, [0,10,20,30,40,50,60,70,80,90,100]),1))
+    print("  end-time deciles (kc):  ", np.round(np.percentile(end, [0,10,20,30,40,50,60,70,80,90,100]),1))
     print(f"  start times: p50 {np.percentile(start,50):.2f} p90 {np.percentile(start,90):.2f} max {start.max():.2f} us")
     tot = st[:, 9]
     print(f"  items per wg: mean {tot.mean():.0f} max {tot.max()}  corr(items, D3 time) {np.corrcoef(tot, st[:,6]-st[:,5])[0,1]:.3f}")
