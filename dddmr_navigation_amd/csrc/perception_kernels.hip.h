@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cstring>
+
 namespace dddmr {
 
 struct FeedParams {
@@ -26,19 +28,24 @@ struct FeedParams {
   float height;           // marking_height_
 };
 
-struct PerceptionScratch {
-  float4* scan_dev = nullptr;
-  unsigned long long* keys = nullptr;  // voxel key per slot (EMPTY = ~0)
-  double* sums = nullptr;              // [slots][3]
-  uint32_t* counts = nullptr;          // [slots]
-  uint32_t* n_out = nullptr;
-  uint32_t* n_out_host = nullptr;      // pinned
-  size_t cap_points = 0;
-  size_t cap_slots = 0;
+struct FeedResult {          // host-mapped: written by the last k_feed_emit workgroup
+  uint32_t n_out;
+  uint32_t seq;              // stored last (system-scope release); the host polls it
 };
 
-constexpr unsigned long long kEmptyKey = ~0ull;
+struct PerceptionScratch {
+  float* scan_dev = nullptr;           // raw scan records (stride_floats apart)
+  unsigned char* table = nullptr;      // [keys 8B | sums 3x8B | counts 4B] x slots, one memset clears it
+  uint32_t* counters = nullptr;        // [0] n_out, [1] ticket
+  FeedResult* res_host = nullptr;      // pinned + mapped
+  FeedResult* res_dev = nullptr;
+  float* stage = nullptr;              // pinned staging for the raw scan
+  size_t cap_points = 0;
+  size_t cap_slots = 0;
+  uint32_t seq = 0;
+};
 
+// key 0 = empty slot (a real key always has bit 63 set)
 __device__ __forceinline__ uint32_t hash_key(unsigned long long k) {
   k ^= k >> 33;
   k *= 0xff51afd7ed558ccdull;
@@ -48,30 +55,31 @@ __device__ __forceinline__ uint32_t hash_key(unsigned long long k) {
   return (uint32_t)k;
 }
 
-__global__ __launch_bounds__(256) void k_feed_insert(FeedParams f, const float4* __restrict__ scan,
+__global__ __launch_bounds__(256) void k_feed_insert(FeedParams f, const float* __restrict__ scan, int stride_floats,
                                                      unsigned long long* __restrict__ keys,
                                                      double* __restrict__ sums, uint32_t* __restrict__ counts,
                                                      uint32_t slot_mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= f.n) return;
-  const float4 s = scan[i];
-  if (!(isfinite(s.x) && isfinite(s.y) && isfinite(s.z))) return;
+  const float* sp = scan + (size_t)i * stride_floats;
+  const float sx = sp[0], sy = sp[1], sz = sp[2];
+  if (!(isfinite(sx) && isfinite(sy) && isfinite(sz))) return;
   // pcl::transformPointCloud(cloud, cloud, Affine3d): double multiply-add, float result
-  const float x = (float)(f.Rbs[0] * s.x + f.Rbs[1] * s.y + f.Rbs[2] * s.z + f.tbs[0]);
-  const float y = (float)(f.Rbs[3] * s.x + f.Rbs[4] * s.y + f.Rbs[5] * s.z + f.tbs[1]);
-  const float z = (float)(f.Rbs[6] * s.x + f.Rbs[7] * s.y + f.Rbs[8] * s.z + f.tbs[2]);
+  const float x = (float)(f.Rbs[0] * sx + f.Rbs[1] * sy + f.Rbs[2] * sz + f.tbs[0]);
+  const float y = (float)(f.Rbs[3] * sx + f.Rbs[4] * sy + f.Rbs[5] * sz + f.tbs[1]);
+  const float z = (float)(f.Rbs[6] * sx + f.Rbs[7] * sy + f.Rbs[8] * sz + f.tbs[2]);
   // pcl::PassThrough keeps limit_min <= v <= limit_max
   if (x < -f.window || x > f.window || y < -f.window || y > f.window || z < 0.0f || z > f.height) return;
   // pcl::VoxelGrid: ijk = floor(p * inverse_leaf_size), leaf 0.1f -> inverse 10.0f
   const float inv_leaf = 1.0f / 0.1f;
   const int ix = (int)floorf(x * inv_leaf), iy = (int)floorf(y * inv_leaf), iz = (int)floorf(z * inv_leaf);
-  const unsigned long long key = ((unsigned long long)(uint32_t)(ix + (1 << 20)) << 42) |
-                                 ((unsigned long long)(uint32_t)(iy + (1 << 20)) << 21) |
-                                 (unsigned long long)(uint32_t)(iz + (1 << 20));
+  const unsigned long long key = (1ull << 63) | ((unsigned long long)((uint32_t)(ix + (1 << 20)) & 0x1FFFFFu) << 42) |
+                                 ((unsigned long long)((uint32_t)(iy + (1 << 20)) & 0x1FFFFFu) << 21) |
+                                 (unsigned long long)((uint32_t)(iz + (1 << 20)) & 0x1FFFFFu);
   uint32_t slot = hash_key(key) & slot_mask;
   for (uint32_t probe = 0; probe <= slot_mask; ++probe) {
-    const unsigned long long prev = atomicCAS(&keys[slot], kEmptyKey, key);
-    if (prev == kEmptyKey || prev == key) {
+    const unsigned long long prev = atomicCAS(&keys[slot], 0ull, key);
+    if (prev == 0ull || prev == key) {
       atomicAdd(&sums[3 * (size_t)slot + 0], (double)x);
       atomicAdd(&sums[3 * (size_t)slot + 1], (double)y);
       atomicAdd(&sums[3 * (size_t)slot + 2], (double)z);
@@ -82,69 +90,128 @@ __global__ __launch_bounds__(256) void k_feed_insert(FeedParams f, const float4*
   }
 }
 
-__global__ __launch_bounds__(256) void k_feed_emit(FeedParams f, const unsigned long long* __restrict__ keys,
-                                                   const double* __restrict__ sums,
-                                                   const uint32_t* __restrict__ counts, uint32_t n_slots,
-                                                   float4* __restrict__ out, uint32_t* __restrict__ n_out) {
+__global__ __launch_bounds__(256) void k_feed_emit(FeedParams f, unsigned long long* __restrict__ keys,
+                                                   double* __restrict__ sums,
+                                                   uint32_t* __restrict__ counts, uint32_t n_slots,
+                                                   float4* __restrict__ out, uint32_t* __restrict__ counters,
+                                                   FeedResult* __restrict__ res, uint32_t seq) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  if (slot >= n_slots) return;
-  if (keys[slot] == kEmptyKey) return;
-  const double n = (double)counts[slot];
-  const float cx = (float)(sums[3 * (size_t)slot + 0] / n);
-  const float cy = (float)(sums[3 * (size_t)slot + 1] / n);
-  const float cz = (float)(sums[3 * (size_t)slot + 2] / n);
-  const float gx = (float)(f.Rgb[0] * cx + f.Rgb[1] * cy + f.Rgb[2] * cz + f.tgb[0]);
-  const float gy = (float)(f.Rgb[3] * cx + f.Rgb[4] * cy + f.Rgb[5] * cz + f.tgb[1]);
-  const float gz = (float)(f.Rgb[6] * cx + f.Rgb[7] * cy + f.Rgb[8] * cz + f.tgb[2]);
-  const uint32_t o = atomicAdd(n_out, 1u);
-  out[o] = make_float4(gx, gy, gz, 0.f);
+  const bool occ = slot < n_slots && keys[slot] != 0ull;
+  // wave-aggregated append: one atomic per wave
+  const unsigned long long mask = __ballot(occ);
+  const int lane = threadIdx.x & 63;
+  uint32_t base = 0;
+  if (mask) {
+    if (lane == (__ffsll((long long)mask) - 1)) base = atomicAdd(&counters[0], (uint32_t)__popcll(mask));
+    base = __shfl(base, __ffsll((long long)mask) - 1, 64);
+  }
+  if (occ) {
+    const double n = (double)counts[slot];
+    const float cx = (float)(sums[3 * (size_t)slot + 0] / n);
+    const float cy = (float)(sums[3 * (size_t)slot + 1] / n);
+    const float cz = (float)(sums[3 * (size_t)slot + 2] / n);
+    const float gx = (float)(f.Rgb[0] * cx + f.Rgb[1] * cy + f.Rgb[2] * cz + f.tgb[0]);
+    const float gy = (float)(f.Rgb[3] * cx + f.Rgb[4] * cy + f.Rgb[5] * cz + f.tgb[1]);
+    const float gz = (float)(f.Rgb[6] * cx + f.Rgb[7] * cy + f.Rgb[8] * cz + f.tgb[2]);
+    const uint32_t o = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    out[o] = make_float4(gx, gy, gz, 0.f);
+    // leave the table empty for the next scan (saves a 2 MB memset per call)
+    keys[slot] = 0ull;
+    sums[3 * (size_t)slot + 0] = 0.0;
+    sums[3 * (size_t)slot + 1] = 0.0;
+    sums[3 * (size_t)slot + 2] = 0.0;
+    counts[slot] = 0u;
+  }
+  // last workgroup publishes the count to the host (device-scope ticket; the count is
+  // only touched by device-scope atomics)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(&counters[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {
+      res->n_out = __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      counters[0] = 0;         // next call
+      counters[1] = 0;
+      __threadfence_system();
+      __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
+
+inline size_t feed_table_bytes(size_t slots) { return slots * (8 + 24 + 4) + 64; }
 
 inline int perception_alloc(PerceptionScratch& s, size_t max_points) {
   s.cap_points = max_points;
   size_t slots = 1024;
   while (slots < 2 * max_points) slots <<= 1;
   s.cap_slots = slots;
-  if (hipMalloc(&s.scan_dev, max_points * sizeof(float4)) != hipSuccess) return -1;
-  if (hipMalloc(&s.keys, slots * sizeof(unsigned long long)) != hipSuccess) return -1;
-  if (hipMalloc(&s.sums, slots * 3 * sizeof(double)) != hipSuccess) return -1;
-  if (hipMalloc(&s.counts, slots * sizeof(uint32_t)) != hipSuccess) return -1;
-  if (hipMalloc(&s.n_out, sizeof(uint32_t)) != hipSuccess) return -1;
-  if (hipHostMalloc(&s.n_out_host, sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) return -1;
+  if (hipMalloc(&s.scan_dev, max_points * 4 * sizeof(float)) != hipSuccess) return -1;
+  if (hipMalloc(&s.table, feed_table_bytes(slots)) != hipSuccess) return -1;
+  if (hipMalloc(&s.counters, 2 * sizeof(uint32_t)) != hipSuccess) return -1;
+  if (hipMemset(s.table, 0, feed_table_bytes(slots)) != hipSuccess) return -1;   // k_feed_emit keeps it clean afterwards
+  if (hipMemset(s.counters, 0, 2 * sizeof(uint32_t)) != hipSuccess) return -1;
+  if (hipHostMalloc(&s.res_host, sizeof(FeedResult), hipHostMallocMapped) != hipSuccess) return -1;
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&s.res_dev), s.res_host, 0) != hipSuccess) return -1;
+  if (hipHostMalloc(&s.stage, max_points * 4 * sizeof(float), hipHostMallocDefault) != hipSuccess) return -1;
+  s.res_host->n_out = 0;
+  s.res_host->seq = 0;
   return 0;
 }
 
 inline void perception_free(PerceptionScratch& s) {
   if (s.scan_dev) (void)hipFree(s.scan_dev);
-  if (s.keys) (void)hipFree(s.keys);
-  if (s.sums) (void)hipFree(s.sums);
-  if (s.counts) (void)hipFree(s.counts);
-  if (s.n_out) (void)hipFree(s.n_out);
-  if (s.n_out_host) (void)hipHostFree(s.n_out_host);
+  if (s.table) (void)hipFree(s.table);
+  if (s.counters) (void)hipFree(s.counters);
+  if (s.res_host) (void)hipHostFree(s.res_host);
+  if (s.stage) (void)hipHostFree(s.stage);
   s = PerceptionScratch();
 }
 
-// scan_host: pinned float4[n] in the sensor frame.  Output: out_dev (global frame).
-inline int perception_feed(PerceptionScratch& s, const FeedParams& f, const float4* scan_host,
+// scan: caller's records (stride_bytes apart, x y z first).  Output: out_dev (global frame).
+inline int perception_feed(PerceptionScratch& s, FeedParams f, const float* scan, size_t stride_bytes,
                            float4* out_dev, hipStream_t stream, uint32_t* n_out) {
   *n_out = 0;
   if (f.n == 0) return 0;
   size_t slots = 1024;
   while (slots < 2 * (size_t)f.n) slots <<= 1;
   if (slots > s.cap_slots) return -2;
-  if (hipMemcpyAsync(s.scan_dev, scan_host, (size_t)f.n * sizeof(float4), hipMemcpyHostToDevice, stream) != hipSuccess) return -3;
-  if (hipMemsetAsync(s.keys, 0xFF, slots * sizeof(unsigned long long), stream) != hipSuccess) return -3;
-  if (hipMemsetAsync(s.sums, 0, slots * 3 * sizeof(double), stream) != hipSuccess) return -3;
-  if (hipMemsetAsync(s.counts, 0, slots * sizeof(uint32_t), stream) != hipSuccess) return -3;
-  if (hipMemsetAsync(s.n_out, 0, sizeof(uint32_t), stream) != hipSuccess) return -3;
-  hipLaunchKernelGGL(k_feed_insert, dim3((f.n + 255) / 256), dim3(256), 0, stream, f, s.scan_dev, s.keys,
-                     s.sums, s.counts, (uint32_t)(slots - 1));
-  hipLaunchKernelGGL(k_feed_emit, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, f, s.keys,
-                     s.sums, s.counts, (uint32_t)slots, out_dev, s.n_out);
-  if (hipMemcpyAsync(s.n_out_host, s.n_out, sizeof(uint32_t), hipMemcpyDeviceToHost, stream) != hipSuccess) return -3;
-  if (hipStreamSynchronize(stream) != hipSuccess) return -4;
+  // stage the raw records in pinned memory: packed xyz(i) records go as they are,
+  // wider ones (PCL: 16/32 bytes) are narrowed to 12 bytes on the way
+  int stride_floats;
+  if (stride_bytes == 12 || stride_bytes == 16) {
+    stride_floats = (int)(stride_bytes / 4);
+    std::memcpy(s.stage, scan, (size_t)f.n * stride_bytes);
+  } else {
+    stride_floats = 3;
+    const size_t sf = stride_bytes / 4;
+    for (size_t i = 0; i < (size_t)f.n; ++i) {
+      s.stage[3 * i + 0] = scan[i * sf + 0];
+      s.stage[3 * i + 1] = scan[i * sf + 1];
+      s.stage[3 * i + 2] = scan[i * sf + 2];
+    }
+  }
+  if (hipMemcpyAsync(s.scan_dev, s.stage, (size_t)f.n * stride_floats * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess) return -3;
+  // fixed layout over the full-capacity table; a call only uses its first `slots` entries
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(s.table);
+  double* sums = reinterpret_cast<double*>(s.table + s.cap_slots * 8);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(s.table + s.cap_slots * 32);
+  const uint32_t seq = ++s.seq ? s.seq : ++s.seq;
+  hipLaunchKernelGGL(k_feed_insert, dim3((f.n + 255) / 256), dim3(256), 0, stream, f, s.scan_dev, stride_floats, keys,
+                     sums, counts, (uint32_t)(slots - 1));
+  hipLaunchKernelGGL(k_feed_emit, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, f, keys, sums, counts,
+                     (uint32_t)slots, out_dev, s.counters, s.res_dev, seq);
   if (hipGetLastError() != hipSuccess) return -5;
-  *n_out = *s.n_out_host;
+  // poll the host-mapped sequence number (bounded), then make sure the stream is idle
+  volatile uint32_t* seq_p = &s.res_host->seq;
+  bool seen = false;
+  for (uint64_t spins = 0; spins < (1ull << 26); ++spins) {
+    if (*seq_p == seq) { seen = true; break; }
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+  }
+  if (!seen && hipStreamSynchronize(stream) != hipSuccess) return -4;
+  *n_out = s.res_host->n_out;
   return 0;
 }
 

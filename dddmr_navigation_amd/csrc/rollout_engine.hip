@@ -493,11 +493,6 @@ int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_po
     return fail(ctx, DDDMR_ERR_CAPACITY, "set_scan: %zu points > max_points %u", n_points, ctx->cfg.max_points);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int back = acquire_back(ctx);
-  const size_t sf = stride_bytes / 4;
-  for (size_t i = 0; i < n_points; ++i) {
-    const float* p = xyz + i * sf;
-    ctx->cloud_stage[i] = make_float4(p[0], p[1], p[2], 0.f);
-  }
   FeedParams fp;
   quat_to_rot(T_base_sensor, fp.Rbs);
   quat_to_rot(T_gbl_base, fp.Rgb);
@@ -509,10 +504,10 @@ int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_po
   fp.window = (float)perception_window_size;
   fp.height = (float)marking_height;
   uint32_t n_out = 0;
-  const int rc = perception_feed(ctx->feed, fp, ctx->cloud_stage, ctx->cloud_dev[back], ctx->copy_stream, &n_out);
+  const int rc = perception_feed(ctx->feed, fp, xyz, stride_bytes, ctx->cloud_dev[back], ctx->copy_stream, &n_out);
   if (rc != 0) return fail(ctx, DDDMR_ERR_HIP, "set_scan: perception feed failed (%d)", rc);
+  // the tick's stream waits on this event, so the feed kernels need not have retired yet
   HIPCHK(ctx, hipEventRecord(ctx->cloud_ready[back], ctx->copy_stream));
-  HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
   publish_cloud(ctx, back, n_out);
   if (n_out_points) *n_out_points = n_out;
   return DDDMR_OK;
