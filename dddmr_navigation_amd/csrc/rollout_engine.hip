@@ -205,6 +205,7 @@ struct dddmr_rollout_ctx {
   Window last_window;
   float cell_size = 0.25f;
   int tile_override = 0;
+  int n_cu = 256;   // compute units of the device
   int timing = 1;   // DDDMR_TIMING: 0 no HIP events, 1 around k_score (score_ms), 2 also around the whole tick
   int timing_every = 1;   // DDDMR_TIMING_EVERY: record the events on every n-th tick only
   int spin = 1;     // DDDMR_SPIN: poll the host-mapped result instead of hipStreamSynchronize
@@ -384,6 +385,11 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
 
   auto init = [&]() -> int {
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    {
+      hipDeviceProp_t prop;
+      HIPCHK(ctx, hipGetDeviceProperties(&prop, ctx->device));
+      ctx->n_cu = std::max(1, prop.multiProcessorCount);
+    }
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     HIPCHK(ctx, hipEventCreate(&ctx->ev0));
@@ -700,17 +706,35 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   k.rows_cap = std::min(kRows, (int)std::floor(std::min(diam, 2.0) * 1.001 / cell) + 2);
 
   // trajectories per workgroup: ~one (trajectory, step) pair per lane
-  // ~160 pairs per 256-thread workgroup measured best on MI355X (C2: tile 3, C3: tile 2):
-  // smaller LDS footprint -> more resident workgroups to cover the serial phases
-  int tile = ctx->tile_override > 0 ? ctx->tile_override : (160 + s_tick / 2) / s_tick;
-  tile = std::min(std::max(tile, 1), kMaxTile);
-  const bool is_omni = th->kind == DDDMR_THEORY_OMNI_SIMPLE;
+  // OBB records carry the pose only if some pair can need the 1 m radius test: a point
+  // inside the box is within max|vertex| of the pose, so a cuboid that lies inside the
+  // search ball never does (the min-max critic always needs it).
+  double vnorm = 0;
+  for (int v = 0; v < 8; ++v)
+    vnorm = std::max(vnorm, std::sqrt((double)th->cuboid[v][0] * th->cuboid[v][0] + (double)th->cuboid[v][1] * th->cuboid[v][1] +
+                                      (double)th->cuboid[v][2] * th->cuboid[v][2]));
+  k.rec_pose = (vnorm >= 0.985 || k.want_minmax) ? 1 : 0;
+  const int rec_words = rec_words_of(k.rec_pose != 0, k.want_minmax != 0);
   {
     const long te = (long)(k.gnx + 1) * k.gny;
     k.tab_entries = (te <= kTabCap && k.n_points >= 5 && (k.want_collision || k.want_minmax)) ? (int)te : 0;
   }
-  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0, k.tab_entries, k.rows_cap) > 72 * 1024) --tile;
-  const size_t lds = score_lds_bytes(tile, s_tick, k.m, is_omni, k.want_minmax != 0, k.tab_entries, k.rows_cap);
+  // Trajectories per workgroup.  ~160 pairs per 256-thread workgroup keep the serial
+  // phases short; but when the whole shard fits ONE round of resident workgroups
+  // (4 per CU at <= 40 KB of LDS) a larger tile that reaches exactly that is faster
+  // than spilling into a second, mostly idle round (measured: 1 round ~56 us for
+  // <= 1024 workgroups, +~20 us for the next 1024).
+  int tile = ctx->tile_override > 0 ? ctx->tile_override : (160 + s_tick / 2) / s_tick;
+  tile = std::min(std::max(tile, 1), kMaxTile);
+  if (ctx->tile_override <= 0 && k.n_local > 0) {
+    const int slots = ctx->n_cu * 4;
+    const int fit = (k.n_local + slots - 1) / slots;          // tile that needs exactly one round
+    if (fit > tile && fit <= kMaxTile && fit * s_tick <= 2 * kScoreThreads &&
+        score_lds_bytes(fit, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) <= 40 * 1024)
+      tile = fit;
+  }
+  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) > 72 * 1024) --tile;
+  const size_t lds = score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap);
   if (lds > (size_t)kScoreLdsMax) return fail(ctx, DDDMR_ERR_CAPACITY, "horizon needs %zu bytes of LDS", lds);
   k.tile = tile;
 

@@ -80,6 +80,7 @@ struct DevTick {
   int axes_inline;
   int use_perm;      // launch-order feedback is valid for this launch shape
   int rows_cap;      // cell rows one cuboid AABB can span with this tick's cell size (<= kRows)
+  int rec_pose;      // OBB records carry the pose (some pair may need the 1 m radius test, or min-max critic)
   uint32_t seq;      // tick sequence number echoed into DevResult::seq
   float axes_inl[kInlineAxes];
 };
@@ -328,14 +329,17 @@ struct TrajHead {     // per-trajectory header in LDS
   double stick_sum;   // StickPathModel: sum of the per-step 1-NN distances
 };
 
-constexpr int kRecWords = 21;       // odd stride: conflict-free field reads across lanes
-constexpr int kRecWordsMM = 27;     // + world AABB for CollisionMinMaxModel
+// OBB record: [0..2] centre, [3..11] axes, [12..14] half extents, [15] cx0|cx1, [16] cy0|cy1,
+// [17] trajectory | radius-skip flag, then (only when some pair can need the radius test)
+// [18..20] pose, then (only for CollisionMinMaxModel) the world AABB
+constexpr int kRecBase = 18;
+__host__ __device__ inline int rec_words_of(bool rec_pose, bool want_mm) { return kRecBase + (rec_pose ? 3 : 0) + (want_mm ? 6 : 0); }
 constexpr int kRows = 8;            // y-rows of cells one cuboid AABB may span (host sizes the cells for it)
 constexpr int kItem = 8;            // points per work item of the collision walk
 constexpr int kTabCap = 4096;       // (gnx+1)*gny row-run boundaries staged in LDS when they fit
 
 // dynamic LDS carve, see k_score (rows are max_steps+1 long):
-__host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m, bool omni, bool want_mm, int tab_entries,
+__host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m, int rec_words, int tab_entries,
                                                   int rows_cap) {
   const size_t S1 = (size_t)max_steps + 1;
   const size_t Q = (size_t)tile * (size_t)max_steps;
@@ -343,15 +347,15 @@ __host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m
   b += sizeof(TrajHead) * (size_t)tile;
   b = (b + 15) & ~(size_t)15;
   b += 16 * (size_t)(m > 0 ? m : 1);                 // plan
-  b += 16 * (size_t)tile * S1 * 2;                   // sc (cos,sin of theta_k) + inc (x,y increments)
-  (void)omni;
-  b += 4 * (size_t)tile * S1;                        // th
   b += 8 * (size_t)tile * S1;                        // xy
   b += 4 * (size_t)tile * S1;                        // dist
-  b += 4 * (size_t)(want_mm ? kRecWordsMM : kRecWords) * Q;   // OBB records
-  b += 4 * (Q * (size_t)rows_cap + 1);               // item prefix sums per non-empty (pair,row) segment
-  b += 8 * (Q * (size_t)rows_cap);                   // segment start + length
+  b += 4 * (size_t)rec_words * Q;                    // OBB records
   b += 4 * (size_t)tab_entries;                      // costmap row-run index (cell_start slice), 0 = not staged
+  b = (b + 15) & ~(size_t)15;
+  // union: {sc, inc, th} live in phases A..D1, {pref, seg_p, seg_len} in D2..D3
+  const size_t u1 = (16 + 16 + 4) * (size_t)tile * S1;
+  const size_t u2 = 4 * (Q * (size_t)rows_cap + 1) + 8 * (Q * (size_t)rows_cap);
+  b += (u1 > u2 ? u1 : u2) + 16;
   b += 64;                                           // scan scratch
   return (b + 15) & ~(size_t)15;
 }
@@ -423,33 +427,36 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   const int Qcap = tile * k.max_steps;
   const bool omni = (k.kind == DDDMR_THEORY_OMNI_SIMPLE);
   const bool need_box = k.want_collision != 0, need_mm = k.want_minmax != 0;
-  const int rec_words = need_mm ? kRecWordsMM : kRecWords;
+  const int rec_words = rec_words_of(k.rec_pose != 0, need_mm);
+  const int mm_ofs = kRecBase + (k.rec_pose ? 3 : 0);
   size_t ofs = 0;
   TrajHead* head = reinterpret_cast<TrajHead*>(lds_raw);
   ofs += sizeof(TrajHead) * (size_t)tile;
   ofs = (ofs + 15) & ~(size_t)15;
   float4* plan = reinterpret_cast<float4*>(lds_raw + ofs);
   ofs += 16 * (size_t)(k.m > 0 ? k.m : 1);
-  double2* sc = reinterpret_cast<double2*>(lds_raw + ofs);
-  ofs += 16 * (size_t)tile * S1;
-  double2* inc = reinterpret_cast<double2*>(lds_raw + ofs);   // body-frame position increments per step
-  ofs += 16 * (size_t)tile * S1;
-  float* th = reinterpret_cast<float*>(lds_raw + ofs);
-  ofs += 4 * (size_t)tile * S1;
   float2* xy = reinterpret_cast<float2*>(lds_raw + ofs);
   ofs += 8 * (size_t)tile * S1;
   float* dist = reinterpret_cast<float*>(lds_raw + ofs);
   ofs += 4 * (size_t)tile * S1;
   float* rec = reinterpret_cast<float*>(lds_raw + ofs);
   ofs += 4 * (size_t)rec_words * Qcap;
-  uint32_t* pref = reinterpret_cast<uint32_t*>(lds_raw + ofs);
-  ofs += 4 * ((size_t)Qcap * k.rows_cap + 1);
-  uint32_t* seg_p = reinterpret_cast<uint32_t*>(lds_raw + ofs);
-  ofs += 4 * (size_t)Qcap * k.rows_cap;
-  uint32_t* seg_len = reinterpret_cast<uint32_t*>(lds_raw + ofs);
-  ofs += 4 * (size_t)Qcap * k.rows_cap;
   uint32_t* tab = reinterpret_cast<uint32_t*>(lds_raw + ofs);
   ofs += 4 * (size_t)k.tab_entries;
+  ofs = (ofs + 15) & ~(size_t)15;
+  // union region: rollout scratch (phases A..D1) / collision segments (phases D2..D3)
+  const size_t uofs = ofs;
+  double2* sc = reinterpret_cast<double2*>(lds_raw + uofs);
+  double2* inc = sc + (size_t)tile * S1;                      // body-frame position increments per step
+  float* th = reinterpret_cast<float*>(inc + (size_t)tile * S1);
+  uint32_t* pref = reinterpret_cast<uint32_t*>(lds_raw + uofs);
+  uint32_t* seg_p = pref + ((size_t)Qcap * k.rows_cap + 1);
+  uint32_t* seg_len = seg_p + (size_t)Qcap * k.rows_cap;
+  {
+    const size_t u1 = (16 + 16 + 4) * (size_t)tile * S1;
+    const size_t u2 = 4 * ((size_t)Qcap * k.rows_cap + 1) + 8 * ((size_t)Qcap * k.rows_cap);
+    ofs += (u1 > u2 ? u1 : u2) + 16;
+  }
   ofs = (ofs + 7) & ~(size_t)7;
   unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(lds_raw + ofs);
 
@@ -701,7 +708,6 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         r[3 + 3 * a + 1] = (float)((double)ey / (2. * h));
         r[3 + 3 * a + 2] = (float)((double)ez / (2. * h));
       }
-      r[15] = px; r[16] = py; r[17] = pz;
       // candidate cells: cuboid AABB clipped to the 1 m search ball's AABB
       const float lox = fmaxf(mnx, px - 1.0f), hix = fminf(mxx, px + 1.0f);
       const float loy = fmaxf(mny, py - 1.0f), hiy = fminf(mxy, py + 1.0f);
@@ -710,12 +716,16 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       cx0 = max(cx0, 0); cy0 = max(cy0, 0);
       cx1 = min(cx1, k.gnx - 1); cy1 = min(cy1, k.gny - 1);
       if (cx0 > cx1 || cy0 > cy1) { cx0 = 1; cx1 = 0; cy0 = 1; cy1 = 0; }
-      reinterpret_cast<int*>(r)[18] = (cx0 & 0xFFFF) | (cx1 << 16);
-      reinterpret_cast<int*>(r)[19] = (cy0 & 0xFFFF) | (cy1 << 16);
+      reinterpret_cast<int*>(r)[15] = (cx0 & 0xFFFF) | (cx1 << 16);
+      reinterpret_cast<int*>(r)[16] = (cy0 & 0xFFFF) | (cy1 << 16);
       // A point inside the (convex) box is no farther from the pose than the farthest
       // vertex, so with all vertices well inside the 1 m ball the radius test is moot.
-      reinterpret_cast<int*>(r)[20] = j | (vmax2 < 0.99f ? 0x10000 : 0);
-      if (need_mm) { r[21] = mnx; r[22] = mny; r[23] = mnz; r[24] = mxx; r[25] = mxy; r[26] = mxz; }
+      reinterpret_cast<int*>(r)[17] = j | ((vmax2 < 0.99f || !k.rec_pose) ? 0x10000 : 0);
+      if (k.rec_pose) { r[18] = px; r[19] = py; r[20] = pz; }
+      if (need_mm) {
+        float* rm = r + mm_ofs;
+        rm[0] = mnx; rm[1] = mny; rm[2] = mnz; rm[3] = mxx; rm[4] = mxy; rm[5] = mxz;
+      }
       if (cy1 - cy0 + 1 > k.rows_cap) atomicOr(overflow, 2u);   // host sizes the cells so this cannot happen
     }
   }
@@ -756,8 +766,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       unsigned long long cnt = 0;
       if (q < total_pairs) {
         const int* ri = reinterpret_cast<const int*>(rec + (size_t)q * rec_words);
-        const int cx0 = (short)(ri[18] & 0xFFFF), cx1 = ri[18] >> 16;
-        const int cy0 = (short)(ri[19] & 0xFFFF), cy1 = ri[19] >> 16;
+        const int cx0 = (short)(ri[15] & 0xFFFF), cx1 = ri[15] >> 16;
+        const int cy0 = (short)(ri[16] & 0xFFFF), cy1 = ri[16] >> 16;
         if (cx0 <= cx1) {
 #pragma unroll
           for (int r = 0; r < kRows; ++r) {
@@ -836,7 +846,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         const uint32_t sl_len = seg_len[sg];
         const int q = (int)(sl_len & 0xFFFu);
         const float* rq = rec + (size_t)q * rec_words;
-        const int jw = reinterpret_cast<const int*>(rq)[20];
+        const int jw = reinterpret_cast<const int*>(rq)[17];
         const int j = jw & 0xFFFF;
         const bool use_radius = (jw & 0x10000) == 0;
         const bool hb = !need_box || head[j].hit_box != 0;
@@ -851,7 +861,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         for (int u = 0; u < kItem; ++u) pt[u] = sorted[p0 + u];
         float r[18];
 #pragma unroll
-        for (int u = 0; u < 18; ++u) r[u] = rq[u];
+        for (int u = 0; u < 15; ++u) r[u] = rq[u];
+        r[15] = r[16] = r[17] = 0.f;             // pose, only read when the radius test is live
+        if (use_radius || need_mm) { r[15] = rq[18]; r[16] = rq[19]; r[17] = rq[20]; }
         bool fb = false, fm = false;
         if (need_box) {
           int hits = 0;
@@ -867,8 +879,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
           for (int u = 0; u < kItem; ++u) {
             // radiusSearch(pose, 1.0): FLANN keeps dist^2 < r^2
             const bool in = (uint32_t)u < n && l2_simple(r[15], r[16], r[17], pt[u].x, pt[u].y, pt[u].z) < 1.0f;
-            fm |= in && (pt[u].x >= rq[21] && pt[u].x <= rq[24] && pt[u].y >= rq[22] && pt[u].y <= rq[25] &&
-                         pt[u].z >= rq[23] && pt[u].z <= rq[26]);
+            const float* rm = rq + mm_ofs;
+            fm |= in && (pt[u].x >= rm[0] && pt[u].x <= rm[3] && pt[u].y >= rm[1] && pt[u].y <= rm[4] &&
+                         pt[u].z >= rm[2] && pt[u].z <= rm[5]);
           }
         }
         if (fb) atomicOr(&head[j].hit_box, 1);
