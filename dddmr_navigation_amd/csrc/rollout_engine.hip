@@ -31,7 +31,7 @@ namespace {
 
 constexpr uint32_t kCapCells = 1u << 20;
 constexpr int kMaxAxis = 4096;
-constexpr int kScoreLdsMax = 96 * 1024;   // dynamic LDS one k_score workgroup may use
+constexpr int kScoreLdsMax = 150 * 1024;   // dynamic LDS one k_score workgroup may use
 
 struct Window {              // result of a theory's initialise()
   std::vector<float> ax, ay, ath;
@@ -205,6 +205,7 @@ struct dddmr_rollout_ctx {
   Window last_window;
   float cell_size = 0.25f;
   int tile_override = 0;
+  int threads_override = 0;   // DDDMR_THREADS: force the 256- or 512-lane k_score
   int n_cu = 256;   // compute units of the device
   int timing = 1;   // DDDMR_TIMING: 0 no HIP events, 1 around k_score (score_ms), 2 also around the whole tick
   int timing_every = 1;   // DDDMR_TIMING_EVERY: record the events on every n-th tick only
@@ -379,6 +380,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     if (v > 0.01f && v < 10.f) ctx->cell_size = v;
   }
   if (const char* e = std::getenv("DDDMR_TILE")) ctx->tile_override = std::atoi(e);
+  if (const char* e = std::getenv("DDDMR_THREADS")) ctx->threads_override = std::atoi(e) == 512 ? 512 : 256;
   if (const char* e = std::getenv("DDDMR_TIMING")) ctx->timing = std::atoi(e);
   if (const char* e = std::getenv("DDDMR_TIMING_EVERY")) ctx->timing_every = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("DDDMR_SPIN")) ctx->spin = std::atoi(e);
@@ -431,7 +433,8 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->result_dev), ctx->result_host, 0));
     const int rc = perception_alloc(ctx->feed, P);
     if (rc != 0) return fail(ctx, DDDMR_ERR_HIP, "perception scratch allocation failed");
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<256>), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
     HIPCHK(ctx, hipDeviceSynchronize());
     return DDDMR_OK;
   };
@@ -724,16 +727,30 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   // (4 per CU at <= 40 KB of LDS) a larger tile that reaches exactly that is faster
   // than spilling into a second, mostly idle round (measured: 1 round ~56 us for
   // <= 1024 workgroups, +~20 us for the next 1024).
-  int tile = ctx->tile_override > 0 ? ctx->tile_override : (160 + s_tick / 2) / s_tick;
+  // Workgroup shape.  Default: 256 lanes, ~160 pairs per workgroup (short serial
+  // phases, many small workgroups in flight: best on big batches).  When the whole
+  // shard fits ONE round of resident 512-lane workgroups (2 per CU at 4 waves per
+  // SIMD and <= 80 KB of LDS), that shape wins: the launch is bound by its heaviest
+  // tile's collision walk and 512 lanes both halve it and average over more
+  // trajectories (measured C2: 59 us vs 67 us; C3/C4 prefer 256).
+  int thr = 256;
+  int tile = (160 + s_tick / 2) / s_tick;
   tile = std::min(std::max(tile, 1), kMaxTile);
-  if (ctx->tile_override <= 0 && k.n_local > 0) {
-    const int slots = ctx->n_cu * 4;
-    const int fit = (k.n_local + slots - 1) / slots;          // tile that needs exactly one round
-    if (fit > tile && fit <= kMaxTile && fit * s_tick <= 2 * kScoreThreads &&
-        score_lds_bytes(fit, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) <= 40 * 1024)
-      tile = fit;
+  if (ctx->tile_override > 0) {
+    tile = std::min(ctx->tile_override, kMaxTile);
+    thr = ctx->threads_override > 0 ? ctx->threads_override : 256;
+  } else if (k.n_local > 0) {
+    const int slots512 = ctx->n_cu * 2;
+    const int fit = (k.n_local + slots512 - 1) / slots512;
+    if (fit <= kMaxTile && fit * s_tick <= 2 * 512 &&
+        score_lds_bytes(fit, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) <= 80 * 1024 &&
+        (ctx->threads_override == 0 || ctx->threads_override == 512)) {
+      thr = 512;
+      tile = std::max(fit, 1);
+    }
+    if (ctx->threads_override == 256) { thr = 256; tile = std::min(std::max((160 + s_tick / 2) / s_tick, 1), kMaxTile); }
   }
-  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) > 72 * 1024) --tile;
+  while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) > (size_t)(160 * 1024) / 2) --tile;
   const size_t lds = score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap);
   if (lds > (size_t)kScoreLdsMax) return fail(ctx, DDDMR_ERR_CAPACITY, "horizon needs %zu bytes of LDS", lds);
   k.tile = tile;
@@ -790,10 +807,16 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     k.use_perm = (wgs > 256 && !std::getenv("DDDMR_NO_PERM")) ? 1 : 0;
     if (k.use_perm && std::getenv("DDDMR_PERM_IDENT")) k.use_perm = 2;   // experiment: keep the books, launch in index order
     ctx->order_tiles = wgs; ctx->order_theory = theory_id; ctx->order_nlocal = k.n_local; ctx->order_seq = k.seq;
-    hipLaunchKernelGGL(k_score, dim3(wgs), dim3(kScoreThreads), lds, ctx->stream, k, ctx->axes_dev,
-                       ctx->samples_dev, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
-                       ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev,
-                       ctx->order, ctx->perm[0], ctx->perm[1]);
+    if (thr == 512)
+      hipLaunchKernelGGL(k_score<512>, dim3(wgs), dim3(512), lds, ctx->stream, k, ctx->axes_dev,
+                         ctx->samples_dev, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
+                         ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev,
+                         ctx->order, ctx->perm[0], ctx->perm[1]);
+    else
+      hipLaunchKernelGGL(k_score<256>, dim3(wgs), dim3(256), lds, ctx->stream, k, ctx->axes_dev,
+                         ctx->samples_dev, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
+                         ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev,
+                         ctx->order, ctx->perm[0], ctx->perm[1]);
   } else {
     hipLaunchKernelGGL(k_empty_result, dim3(1), dim3(64), 0, ctx->stream, k, ctx->cell_start, ctx->result_dev);
   }

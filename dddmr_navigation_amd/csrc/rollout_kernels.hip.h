@@ -29,7 +29,10 @@ namespace dddmr {
 #ifndef DDDMR_SCORE_WPE
 #define DDDMR_SCORE_WPE 2   // min waves per SIMD the register allocator must allow for k_score
 #endif
-constexpr int kScoreThreads = 256;
+// k_score is instantiated for 256- and 512-lane workgroups (template parameter
+// kScoreThreads): 512 lanes halve the collision walk of the heaviest tile and win when
+// the shard fits one round of resident workgroups (C2); 256 lanes keep more, smaller
+// workgroups in flight and win on big batches (C3, C4).
 constexpr int kBinThreads = 1024;     // k_bin_count workgroup (its last workgroup scans 4096 cells per step)
 constexpr int kMaxTile = 16;          // trajectories per workgroup (upper bound)
 constexpr int kMaxPlan = 512;         // prune-plan poses kept in LDS
@@ -414,6 +417,7 @@ __device__ __forceinline__ bool box_test(const float* r, float x, float y, float
   return xv <= r[12] && yv <= r[13] && zv <= r[14];
 }
 
+template <int kScoreThreads>
 __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     DevTick k, const float* __restrict__ axes, const float4* __restrict__ samples,
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
