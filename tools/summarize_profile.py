@@ -12,7 +12,8 @@ os.makedirs(dst, exist_ok=True)
 
 def short(name):
     n = name.split("(")[0]
-    return n.replace("dddmr::", "").replace("void ", "").strip()
+    n = n.replace("dddmr::", "").replace("void ", "").strip()
+    return n.split("<")[0] if n.startswith("k_") else n
 
 # ---- kernel stats ----
 rows = []
