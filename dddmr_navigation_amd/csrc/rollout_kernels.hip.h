@@ -338,7 +338,10 @@ struct TrajHead {     // per-trajectory header in LDS
 constexpr int kRecBase = 18;
 __host__ __device__ inline int rec_words_of(bool rec_pose, bool want_mm) { return kRecBase + (rec_pose ? 3 : 0) + (want_mm ? 6 : 0); }
 constexpr int kRows = 8;            // y-rows of cells one cuboid AABB may span (host sizes the cells for it)
-constexpr int kItem = 8;            // points per work item of the collision walk
+#ifndef DDDMR_ITEM
+#define DDDMR_ITEM 8
+#endif
+constexpr int kItem = DDDMR_ITEM;            // points per work item of the collision walk
 constexpr int kTabCap = 4096;       // (gnx+1)*gny row-run boundaries staged in LDS when they fit
 
 // dynamic LDS carve, see k_score (rows are max_steps+1 long):

@@ -1,0 +1,72 @@
+"""Host-side pieces of the local planner that stay on the CPU (SURVEY.md 8a rows a18
+and the heading predicates): tiny, sequential, and their outputs are INPUTS of the
+rollout engine.  Restated from
+/root/reference/src/dddmr_local_planner/local_planner/src/local_planner.cpp
+with the same quirks (cited inline); the C++ twin is in include/dddmr_rollout.hpp.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+
+
+def prune_plan(global_plan: np.ndarray, robot_xyz, forward_distance: float, backward_distance: float) -> Optional[np.ndarray]:
+    """Local_Planner::prunePlan (local_planner.cpp:374-445).
+
+    global_plan: [G,7] poses (x y z qx qy qz qw).  Returns the prune plan [M,7], or
+    None where the reference returns without touching prune_plan_ (fewer than 3
+    poses :376-377, or the robot is more than 1 m off the plan :395-399).
+
+    Quirk kept on purpose: the nearest pose is pushed twice (once by the backward
+    walk, once by the forward walk, :404 and :421).  Both walks stop at the first
+    pose whose accumulated distance EXCEEDS the budget (that pose is included).
+    """
+    plan = np.ascontiguousarray(global_plan, dtype=np.float64).reshape(-1, 7)
+    if len(plan) < 3:
+        return None
+    # 1-NN on the float point cloud of the plan with FLANN's float distance (:389)
+    pf = plan[:, :3].astype(np.float32)
+    q = np.asarray(robot_xyz, dtype=np.float64).astype(np.float32)
+    d = pf - q
+    d2 = (d[:, 0] * d[:, 0]).astype(np.float32)
+    d2 = (d2 + d[:, 1] * d[:, 1]).astype(np.float32)
+    d2 = (d2 + d[:, 2] * d[:, 2]).astype(np.float32)
+    idx = int(np.argmin(d2))
+    if math.sqrt(float(d2[idx])) > 1.0:
+        return None
+
+    def dist(a, b):
+        return math.sqrt((a[0] - b[0]) ** 2 + (a[1] - b[1]) ** 2 + (a[2] - b[2]) ** 2)
+
+    out = []
+    last = plan[idx]
+    bd = backward_distance
+    for i in range(idx, -1, -1):            # backward check (:403-415)
+        out.append(plan[i])
+        if i < idx:
+            bd -= dist(last, plan[i])
+        last = plan[i]
+        if bd < 0:
+            break
+    out.reverse()
+    fd = forward_distance
+    for i in range(idx, len(plan)):          # forward check (:420-438); last := plan[idx] at i == idx (:435)
+        out.append(plan[i])
+        if i > idx:
+            fd -= dist(last, plan[i])
+        last = plan[i]
+        if fd < 0:
+            break
+    return np.array(out, dtype=np.float64)
+
+
+def is_goal_reached(global_plan: np.ndarray, robot_xyz, xy_goal_tolerance: float) -> bool:
+    """Local_Planner::isGoalReached (local_planner.cpp:305-320): 3-D distance to the
+    last pose strictly below the tolerance."""
+    plan = np.asarray(global_plan, dtype=np.float64).reshape(-1, 7)
+    if len(plan) == 0:
+        return False
+    d = np.asarray(robot_xyz, dtype=np.float64) - plan[-1, :3]
+    return bool(xy_goal_tolerance > math.sqrt(float(d @ d)))
