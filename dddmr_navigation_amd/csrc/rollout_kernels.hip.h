@@ -411,15 +411,6 @@ __device__ __forceinline__ void pose_translation(const DevTick& k, float2 bxy, d
   for (int i = 0; i < 3; ++i) T[i] = k.R[3 * i + 0] * (double)bxy.x + k.R[3 * i + 1] * (double)bxy.y + k.t[i];
 }
 
-__device__ __forceinline__ bool box_test(const float* r, float x, float y, float z) {
-  // collision_model.cpp:124-139, float arithmetic in source order
-  const float dx = fsub(x, r[0]), dy = fsub(y, r[1]), dz = fsub(z, r[2]);
-  const float xv = fabsf(dot3(dx, dy, dz, r[3], r[4], r[5]));
-  const float yv = fabsf(dot3(dx, dy, dz, r[6], r[7], r[8]));
-  const float zv = fabsf(dot3(dx, dy, dz, r[9], r[10], r[11]));
-  return xv <= r[12] && yv <= r[13] && zv <= r[14];
-}
-
 template <int kScoreThreads>
 __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     DevTick k, const float* __restrict__ axes, const float4* __restrict__ samples,
