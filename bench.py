@@ -62,6 +62,10 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # fail early (and loudly) if RCCL cannot move 8 bytes between the ranks
+            probe = torch.full((1,), rank, dtype=torch.int64, device=dev)
+            dist.all_reduce(probe, op=dist.ReduceOp.MIN)
+            assert int(probe.item()) == 0
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")

@@ -64,3 +64,28 @@ def test_tick_on_fed_cloud_equals_tick_on_oracle_cloud():
     assert (c1 == -1.0).any() and (c1 >= 0).any()
     if not ((c1 != c2).any()):
         assert r1.best_index == r2.best_index == o.result.best_index
+
+
+def test_set_scan_edge_cases():
+    th = configs.bench_theory("C1")
+    ident = (0, 0, 0, 0, 0, 0, 1)
+    with LocalPlanner([th], max_points=4096) as lp:
+        # empty scan -> empty cloud
+        assert lp.set_scan(np.zeros((0, 3), np.float32), ident, ident, 5.0, 2.0) == 0
+        assert len(lp.get_cloud()) == 0
+        # everything cropped (outside the window / below z = 0 / NaN)
+        junk = np.array([[50, 0, 1], [0, -50, 1], [1, 1, -0.5], [1, 1, 9], [np.nan, 0, 0], [np.inf, 0, 1]], np.float32)
+        assert lp.set_scan(junk, ident, ident, 5.0, 2.0) == 0
+        # PCL-style 32-byte records, limits are inclusive
+        wide = np.zeros((3, 8), np.float32)
+        wide[:, :3] = [[5.0, -5.0, 2.0], [5.0, -5.0, 2.0], [0.05, 0.05, 0.0]]
+        assert lp.set_scan(wide, ident, ident, 5.0, 2.0) == 2
+        got = lp.get_cloud()
+        ref = oracle.feed(wide[:, :3].copy(), ident, ident, 5.0, 2.0)
+        assert sorted(map(tuple, np.round(got[:, :3], 5))) == sorted(map(tuple, np.round(ref, 5)))
+        # too many points -> capacity error, context stays usable
+        from dddmr_navigation_amd.local_planner import RolloutError
+        with pytest.raises(RolloutError) as e:
+            lp.set_scan(np.zeros((5000, 3), np.float32), ident, ident, 5.0, 2.0)
+        assert e.value.code == K.ERR_CAPACITY
+        assert lp.set_scan(wide, ident, ident, 5.0, 2.0) == 2

@@ -356,6 +356,32 @@ def test_c4_batch_65536_sharded_over_8_contexts():
     assert sharding.key_index(min(keys)) == res0.best_index
 
 
+def test_moving_robot_sequence_keeps_parity():
+    """State carried between ticks (launch-order feedback, double-buffered cloud,
+    sampled timing) must never leak into results: a robot driving down the C2
+    corridor, new pose / twist / cloud subset every tick, each tick vs the oracle."""
+    sc = scenes.bench_scene("C2")
+    th = configs.omni_simple_shipped(linear_x_sample=12.0, linear_y_sample=12.0, angular_z_sample=12.0)
+    name = th.name.decode()
+    rng = np.random.default_rng(3)
+    with LocalPlanner([th], max_points=len(sc.cloud)) as lp:
+        lp.setPlan(sc.plan)
+        for t in range(14):
+            x = -0.5 + 0.25 * t
+            pose = (x, 0.5 * math.sin(0.5 * x), 0.0) + scenes.quat_from_rpy(0, 0, 0.2 * math.sin(t))
+            tick = scenes.tick_input(pose=pose, twist=(0.3 + 0.02 * t, 0.05 * math.cos(t), 0.1 * math.sin(t)))
+            cloud = sc.cloud if t % 3 else sc.cloud[rng.random(len(sc.cloud)) < 0.7]
+            lp.set_cloud(cloud)
+            res = lp.tick(name, tick)
+            costs, steps, smp = lp.debug()
+            o = oracle.tick(th, cloud, sc.plan, tick, n_threads=8, want_margin=True)
+            flips = check_arrays(costs, steps, smp, o.costs, o.steps, o.samples, o.min_margin)
+            if flips == 0 and res.best_index != o.result.best_index:
+                assert abs(costs[res.best_index] - o.costs[o.result.best_index]) <= 1e-6      # sub-noise near-tie
+            elif flips == 0:
+                check_cmd(res, o.result.planner_state, o.result.best_index, o.result.best_cost, o.result.vx, o.result.vy, o.result.wz)
+
+
 def test_set_cloud_from_sensor_thread_while_ticking():
     sc = scenes.bench_scene("C1")
     name = sc.theory.name.decode()
