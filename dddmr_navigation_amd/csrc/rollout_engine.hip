@@ -360,6 +360,8 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
   if (cfg->n_theories <= 0 || !cfg->theories) return DDDMR_ERR_BAD_ARG;
   if (cfg->max_points == 0 || cfg->max_trajectories == 0 || cfg->max_steps == 0) return DDDMR_ERR_BAD_ARG;
   if (cfg->max_trajectories >= (1u << kKeyIndexBits)) return DDDMR_ERR_CAPACITY;
+  if (cfg->max_points >= (1u << 20)) return DDDMR_ERR_CAPACITY;   // a row run's length is packed into 20 bits
+  if (cfg->max_steps > 4096) return DDDMR_ERR_CAPACITY;          // a pair index is packed into 12 bits
   if (cfg->max_plan_poses > (uint32_t)kMaxPlan) return DDDMR_ERR_CAPACITY;
   for (int i = 0; i < cfg->n_theories; ++i) {
     const auto& t = cfg->theories[i];

@@ -155,10 +155,10 @@ typedef struct {
      world_size <= 1 means the whole batch. */
   int32_t rank;
   int32_t world_size;
-  uint32_t max_points;       /* capacity of the aggregate observation cloud */
-  uint32_t max_trajectories; /* capacity of one tick's sample list (global N) */
-  uint32_t max_steps;        /* capacity of one trajectory's horizon */
-  uint32_t max_plan_poses;   /* capacity of the prune plan */
+  uint32_t max_points;       /* capacity of the aggregate observation cloud (< 2^20) */
+  uint32_t max_trajectories; /* capacity of one tick's sample list (global N, < 2^24) */
+  uint32_t max_steps;        /* capacity of one trajectory's horizon (<= 4096) */
+  uint32_t max_plan_poses;   /* capacity of the prune plan (<= 512) */
   int32_t n_theories;
   int32_t reserved;
   const dddmr_theory_config* theories;

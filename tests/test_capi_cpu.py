@@ -91,6 +91,16 @@ def test_create_rejects_bad_arguments():
     cfg.abi_version = K.ABI_VERSION
     assert lib.dddmr_rollout_create(C.byref(cfg), C.byref(ctx)) == K.ERR_BAD_ARG   # no theories
     assert not ctx.value
+    # capacity limits that do not depend on the device
+    th = configs.theory_array(configs.shipped_theories())
+    cfg.n_theories = len(th)
+    cfg.theories = C.cast(th, C.POINTER(K.TheoryConfig))
+    cfg.max_points, cfg.max_trajectories, cfg.max_steps, cfg.max_plan_poses = 1 << 20, 1024, 64, 64
+    assert lib.dddmr_rollout_create(C.byref(cfg), C.byref(ctx)) == K.ERR_CAPACITY
+    cfg.max_points, cfg.max_trajectories = 1024, 1 << 24
+    assert lib.dddmr_rollout_create(C.byref(cfg), C.byref(ctx)) == K.ERR_CAPACITY
+    cfg.max_trajectories, cfg.max_plan_poses = 1024, 100000
+    assert lib.dddmr_rollout_create(C.byref(cfg), C.byref(ctx)) == K.ERR_CAPACITY
 
 
 def test_shipped_configs_restate_yaml():
