@@ -154,6 +154,11 @@ struct dddmr_rollout_ctx {
   std::vector<dddmr_theory_config> theories;
   int device = 0;
   hipStream_t stream = nullptr, copy_stream = nullptr;
+  // k_rollout state arrays, grown on demand: [n_local][max steps of the tick]
+  TrajInfo* traj_info = nullptr;
+  double2* st_sc = nullptr;
+  float2* st_xy = nullptr;
+  size_t st_cap = 0;       // (trajectory, step) pairs the state arrays hold
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr, cloud_ready[2] = {nullptr, nullptr};
 
   // device memory
@@ -350,6 +355,9 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   if (ctx->evs1) (void)hipEventDestroy(ctx->evs1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+  if (ctx->traj_info) (void)hipFree(ctx->traj_info);
+  if (ctx->st_sc) (void)hipFree(ctx->st_sc);
+  if (ctx->st_xy) (void)hipFree(ctx->st_xy);
   delete ctx;
 }
 
@@ -435,6 +443,8 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&ctx->result_dev), ctx->result_host, 0));
     const int rc = perception_alloc(ctx->feed, P);
     if (rc != 0) return fail(ctx, DDDMR_ERR_HIP, "perception scratch allocation failed");
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_count), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<256>), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
     HIPCHK(ctx, hipDeviceSynchronize());
@@ -777,6 +787,23 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
       std::memcpy(a + k.ath_ofs, w.ath.data(), w.ath.size() * sizeof(float));
       HIPCHK(ctx, hipMemcpyAsync(ctx->axes_dev, a, 3 * kMaxAxis * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
+    // state arrays of the body-frame rollout
+    const size_t need = (size_t)k.n_local * (size_t)s_tick;
+    if (need > ctx->st_cap || !ctx->traj_info) {
+      HIPCHK(ctx, hipDeviceSynchronize());
+      if (ctx->st_sc) (void)hipFree(ctx->st_sc);
+      if (ctx->st_xy) (void)hipFree(ctx->st_xy);
+      ctx->st_sc = nullptr; ctx->st_xy = nullptr; ctx->st_cap = 0;
+      const size_t cap = need + need / 4 + 1024;
+      HIPCHK(ctx, hipMalloc(&ctx->st_sc, cap * sizeof(double2)));
+      HIPCHK(ctx, hipMalloc(&ctx->st_xy, cap * sizeof(float2)));
+      ctx->st_cap = cap;
+      if (!ctx->traj_info) HIPCHK(ctx, hipMalloc(&ctx->traj_info, (size_t)ctx->cfg.max_trajectories * sizeof(TrajInfo)));
+    }
+    // rollout workgroups ride along with k_bin_count (1024 lanes, one resident per CU)
+    int rt = std::min(std::max((k.n_local + ctx->n_cu - 1) / ctx->n_cu, 4), 64);
+    while (rt > 1 && rollout_lds_bytes(rt, s_tick) > (size_t)128 * 1024) --rt;
+    k.rt = rt;
   }
   if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
 
@@ -788,14 +815,21 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   if (timed_all) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   const int bin_blocks = std::max(1, std::min(2048, (k.n_points + 255) / 256));
   const int cnt_blocks = std::max(1, std::min(512, (k.n_points + kBinThreads - 1) / kBinThreads));
+  const int roll_blocks = k.n_local > 0 ? (k.n_local + k.rt - 1) / k.rt : 0;
+  const size_t roll_lds = k.n_local > 0 ? rollout_lds_bytes(k.rt, s_tick) : 0;
+  k.bin_blocks = cnt_blocks;
   if (k.n_points > 0) {
-    hipLaunchKernelGGL(k_bin_count, dim3(cnt_blocks), dim3(kBinThreads), 0, ctx->stream, k, ctx->cloud_dev[cidx],
-                       ctx->cell_count, ctx->cell_start, ctx->pt_slot, ctx->tickets, ctx->best_key, ctx->overflow);
+    hipLaunchKernelGGL(k_bin_count, dim3(cnt_blocks + roll_blocks), dim3(kBinThreads), roll_lds, ctx->stream, k,
+                       ctx->cloud_dev[cidx], ctx->cell_count, ctx->cell_start, ctx->pt_slot, ctx->tickets, ctx->best_key,
+                       ctx->overflow, ctx->axes_dev, ctx->samples_dev, ctx->traj_info, ctx->st_sc, ctx->st_xy);
     hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks), dim3(256), 0, ctx->stream, k, ctx->cloud_dev[cidx],
                        ctx->pt_slot, ctx->cell_start, ctx->sorted);
   } else {
     hipLaunchKernelGGL(k_bin_reset, dim3(1), dim3(256), 0, ctx->stream, k, ctx->cell_count, ctx->cell_start,
                        ctx->best_key, ctx->overflow);
+    if (roll_blocks > 0)
+      hipLaunchKernelGGL(k_rollout, dim3(roll_blocks), dim3(256), roll_lds, ctx->stream, k, ctx->axes_dev,
+                         ctx->samples_dev, ctx->traj_info, ctx->st_sc, ctx->st_xy);
   }
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
   if (k.n_local > 0) {
@@ -810,13 +844,13 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     if (k.use_perm && std::getenv("DDDMR_PERM_IDENT")) k.use_perm = 2;   // experiment: keep the books, launch in index order
     ctx->order_tiles = wgs; ctx->order_theory = theory_id; ctx->order_nlocal = k.n_local; ctx->order_seq = k.seq;
     if (thr == 512)
-      hipLaunchKernelGGL(k_score<512>, dim3(wgs), dim3(512), lds, ctx->stream, k, ctx->axes_dev,
-                         ctx->samples_dev, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
+      hipLaunchKernelGGL(k_score<512>, dim3(wgs), dim3(512), lds, ctx->stream, k, ctx->traj_info,
+                         ctx->st_sc, ctx->st_xy, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
                          ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev,
                          ctx->order, ctx->perm[0], ctx->perm[1]);
     else
-      hipLaunchKernelGGL(k_score<256>, dim3(wgs), dim3(256), lds, ctx->stream, k, ctx->axes_dev,
-                         ctx->samples_dev, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
+      hipLaunchKernelGGL(k_score<256>, dim3(wgs), dim3(256), lds, ctx->stream, k, ctx->traj_info,
+                         ctx->st_sc, ctx->st_xy, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
                          ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev,
                          ctx->order, ctx->perm[0], ctx->perm[1]);
   } else {

@@ -83,6 +83,8 @@ struct DevTick {
   int axes_inline;
   int use_perm;      // launch-order feedback is valid for this launch shape
   int rows_cap;      // cell rows one cuboid AABB can span with this tick's cell size (<= kRows)
+  int rt;            // trajectories per rollout workgroup
+  int bin_blocks;    // binning workgroups of the k_bin_count launch (the rest roll out)
   int rec_pose;      // OBB records carry the pose (some pair may need the 1 m radius test, or min-max critic)
   uint32_t seq;      // tick sequence number echoed into DevResult::seq
   float axes_inl[kInlineAxes];
@@ -220,51 +222,6 @@ __device__ inline void scan_cells(const DevTick& k, uint32_t* __restrict__ cell_
   if (tid == 0) cell_start[n] = *carry_s;
 }
 
-// Crop the cloud to the local costmap tile and count points per cell; the LAST
-// workgroup to finish (device-scope ticket) scans the counters, so binning is two
-// launches, not three.  Also resets the argmin key / capacity flag of the tick.
-__global__ __launch_bounds__(kBinThreads) void k_bin_count(DevTick k, const float4* __restrict__ cloud,
-                                                   uint32_t* __restrict__ cell_count,
-                                                   uint32_t* __restrict__ cell_start,
-                                                   uint2* __restrict__ pt_slot, uint32_t* __restrict__ ticket,
-                                                   int64_t* __restrict__ best_key,
-                                                   uint32_t* __restrict__ overflow) {
-  __shared__ uint32_t wave_sum[16];
-  __shared__ uint32_t carry_s;
-  __shared__ uint32_t is_last;
-  const int stride = gridDim.x * blockDim.x;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k.n_points; i += stride) {
-    const float4 p = cloud[i];
-    uint2 slot = make_uint2(0xFFFFFFFFu, 0u);
-    const bool in = p.x >= k.rmin[0] && p.x <= k.rmax[0] && p.y >= k.rmin[1] && p.y <= k.rmax[1] &&
-                    p.z >= k.rmin[2] && p.z <= k.rmax[2];
-    if (in) {
-      const int c = cell_of(k, p.x, p.y, p.z);
-      slot.x = (uint32_t)c;
-      slot.y = atomicAdd(&cell_count[c], 1u);
-    }
-    pt_slot[i] = slot;
-  }
-  // Ticket.  The only data handed to the last workgroup are the cell counters, and
-  // those are touched exclusively by device-scope atomics (returned => performed)
-  // and read back with device-scope atomic loads, so no cache write-back /
-  // invalidate is needed: every wave drains its atomics, barrier, one relaxed
-  // device-scope add per workgroup.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = (t == gridDim.x - 1) ? 1u : 0u;
-    if (is_last) {
-      *ticket = 0;            // next tick
-      *best_key = kKeyNone;
-      *overflow = 0;
-    }
-  }
-  __syncthreads();
-  if (is_last) scan_cells(k, cell_count, cell_start, wave_sum, &carry_s);
-}
-
 // Empty cloud: only the scan/reset part.
 __global__ __launch_bounds__(256) void k_bin_reset(DevTick k, uint32_t* __restrict__ cell_count,
                                                    uint32_t* __restrict__ cell_start,
@@ -288,6 +245,242 @@ __global__ __launch_bounds__(256) void k_bin_scatter(DevTick k, const float4* __
     const uint2 slot = pt_slot[i];
     if (slot.x != 0xFFFFFFFFu) sorted[cell_start[slot.x] + slot.y] = cloud[i];
   }
+}
+
+// ---------------------------------------------------------------------------
+// k_rollout: body-frame forward simulation of every sample of the shard
+// (generateTrajectory + computeNewPositions of the three theories).  It depends on
+// neither the robot pose nor the cloud, so it runs as extra workgroups of the
+// k_bin_count launch (which leaves most of the chip idle).  One workgroup = k.rt trajectories:
+//   A  one lane per trajectory: sample decode, generation gates, step count,
+//      theta recurrence theta <- float(double(theta) + w*dt)  (2 dependent ops/step)
+//   B  all lanes: double sin/cos of every theta_k (and of pi/2 + theta_k for omni);
+//      the position increment of step k only depends on theta_k and is formed here
+//   C  one lane per trajectory: x,y running sum p <- float(double(p) + inc)
+// Output per (trajectory, step): body-frame x,y after the step (float2) and
+// cos/sin of the heading after the step (double2, the pose's AngleAxisd rotation).
+// ---------------------------------------------------------------------------
+struct TrajInfo {      // per trajectory, 32 bytes
+  float vx, vy, w;
+  int steps;           // 0 = not generated
+  double dt;
+  int over;            // step count exceeded the context's max_steps (capacity error)
+  int pad;
+};
+
+__host__ __device__ inline size_t rollout_lds_bytes(int rt, int max_steps) {
+  return (size_t)rt * (size_t)(max_steps + 1) * (4 + 16) + 16;
+}
+
+template <int kThreads>
+__device__ __forceinline__ void rollout_block(const DevTick& k, const int block, const float* __restrict__ axes,
+                                              const float4* __restrict__ samples, TrajInfo* __restrict__ info,
+                                              double2* __restrict__ st_sc, float2* __restrict__ st_xy,
+                                              unsigned char* roll_lds) {
+  const int S1 = k.max_steps + 1;
+  const int rt = k.rt;
+  double2* inc = reinterpret_cast<double2*>(roll_lds);                  // [rt][S1]
+  float* th = reinterpret_cast<float*>(inc + (size_t)rt * S1);           // [rt][S1]
+  __shared__ int steps_s[64];
+  __shared__ float vel_s[64][3];
+  __shared__ double dt_s[64];
+  const int tid = threadIdx.x;
+  const int l0 = block * rt;                          // first local trajectory of this workgroup
+  const int nt = min(rt, k.n_local - l0);
+  const bool omni = (k.kind == DDDMR_THEORY_OMNI_SIMPLE);
+
+  // ---- phase A ----
+  if (tid < nt) {
+    const int li = l0 + tid;
+    const int gi = k.begin + li;
+    float vx, vy, w;
+    if (k.list_mode) {
+      const float4 sm = samples[gi];
+      vx = sm.x; vy = sm.y; w = sm.z;
+    } else {
+      const int ith = gi % k.nth;
+      const int r = gi / k.nth;
+      const int iy = r % k.ny;
+      const int ix = r / k.ny;
+      if (k.axes_inline) {
+        vx = k.axes_inl[ix];
+        vy = k.axes_inl[k.ay_ofs + iy];
+        w = k.axes_inl[k.ath_ofs + ith];
+      } else {
+        vx = axes[ix];
+        vy = axes[k.ay_ofs + iy];
+        w = axes[k.ath_ofs + ith];
+      }
+    }
+    int over = 0;
+    const double eps = 1e-4;
+    bool ok = true;
+    double vmag, sim_time = k.sim_time;
+    if (k.kind == DDDMR_THEORY_DD_SIMPLE) {
+      // dd_simple_trajectory_generator_theory.cpp:364-371
+      vmag = fabs((double)vx);
+      if ((k.min_vel_x >= 0 && vmag + eps < k.min_vel_x) &&
+          (k.min_vel_theta >= 0 && fabs((double)w) + eps < k.min_vel_theta)) ok = false;
+      if (k.max_vel_x >= 0 && vmag - eps > k.max_vel_x) ok = false;
+    } else if (omni) {
+      // omni_simple_trajectory_generator_theory.cpp:387-411
+      vmag = hypot((double)vx, (double)vy);
+      if ((k.min_vel_trans >= 0 && vmag + eps < k.min_vel_trans) &&
+          (k.min_vel_theta >= 0 && fabs((double)w) + eps < k.min_vel_theta)) ok = false;
+      if (k.max_vel_trans >= 0 && vmag - eps > k.max_vel_trans) ok = false;
+      if (k.allowed_max > 0.0 && vmag - eps > k.allowed_max) ok = false;
+    } else {
+      // dd_rotate_inplace_theory.cpp:337: one full turn
+      vmag = fabs((double)vx);
+      sim_time = 6.28 / fabs((double)w);
+    }
+    int ns = 0;
+    if (ok) {
+      if (k.fixed_steps > 0) {
+        ns = k.fixed_steps;
+      } else {
+        const double sd = vmag * sim_time;
+        const double sa = fabs((double)w) * sim_time;
+        ns = (int)ceil(fmax(sd / k.sim_gran, sa / k.ang_gran));
+      }
+      if (ns > k.max_steps) {       // capacity error, reported to the host by k_score
+        over = 1;
+        ns = 0;
+      }
+    }
+    const double dt = ns > 0 ? sim_time / (double)ns : 0.0;
+    TrajInfo ti;
+    ti.vx = vx; ti.vy = vy; ti.w = w;
+    ti.steps = ns;
+    ti.dt = dt;
+    ti.over = over;
+    ti.pad = 0;
+    info[li] = ti;
+    steps_s[tid] = ns;
+    vel_s[tid][0] = vx; vel_s[tid][1] = vy; vel_s[tid][2] = w;
+    dt_s[tid] = dt;
+    // theta_{k+1} = float(theta_k + w*dt)   (computeNewPositions, dd_simple...cpp:457-464)
+    float* row = th + (size_t)tid * S1;
+    float a = 0.f;
+    row[0] = 0.f;
+    const double wdt = (double)w * dt;
+    for (int s = 1; s <= ns; ++s) {
+      a = (float)((double)a + wdt);
+      row[s] = a;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B ----
+  for (int idx = tid; idx < nt * S1; idx += kThreads) {
+    const int j = idx / S1, s = idx - j * S1;
+    const int ns = steps_s[j];
+    if (s <= ns) {
+      const double a = (double)th[(size_t)j * S1 + s];
+      double sn, cs;
+      sincos(a, &sn, &cs);
+      // heading after step s-1 = theta_s: the pose's rotation (dd_simple...cpp:416)
+      if (s >= 1) st_sc[(size_t)(l0 + j) * k.max_steps + (s - 1)] = make_double2(cs, sn);
+      if (s < ns) {
+        const float vx = vel_s[j][0], vy = vel_s[j][1];
+        const float cf = (float)cs, sf = (float)sn;      // cos/sin(float) overloads
+        double ix = (double)fmul(vx, cf), iy = (double)fmul(vx, sf);
+        if (omni) {
+          // cos/sin(M_PI_2 + theta) in double (omni_simple...cpp:501-502)
+          double s2, c2;
+          sincos(M_PI_2 + a, &s2, &c2);
+          ix += (double)vy * c2;
+          iy += (double)vy * s2;
+        }
+        inc[(size_t)j * S1 + s] = make_double2(ix * dt_s[j], iy * dt_s[j]);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase C ----
+  if (tid < nt) {
+    const int ns = steps_s[tid];
+    const double2* ir = inc + (size_t)tid * S1;
+    float2* xr = st_xy + (size_t)(l0 + tid) * k.max_steps;
+    float px = 0.f, py = 0.f;
+    int s = 0;
+    for (; s + 4 <= ns; s += 4) {
+      const double2 i0 = ir[s], i1 = ir[s + 1], i2 = ir[s + 2], i3 = ir[s + 3];
+      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); xr[s] = make_float2(px, py);
+      px = (float)((double)px + i1.x); py = (float)((double)py + i1.y); xr[s + 1] = make_float2(px, py);
+      px = (float)((double)px + i2.x); py = (float)((double)py + i2.y); xr[s + 2] = make_float2(px, py);
+      px = (float)((double)px + i3.x); py = (float)((double)py + i3.y); xr[s + 3] = make_float2(px, py);
+    }
+    for (; s < ns; ++s) {
+      const double2 i0 = ir[s];
+      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); xr[s] = make_float2(px, py);
+    }
+  }
+}
+
+// Stand-alone launch (empty cloud: there is no k_bin_count to ride along with).
+__global__ __launch_bounds__(256) void k_rollout(DevTick k, const float* __restrict__ axes,
+                                                 const float4* __restrict__ samples,
+                                                 TrajInfo* __restrict__ info, double2* __restrict__ st_sc,
+                                                 float2* __restrict__ st_xy) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  rollout_block<256>(k, (int)blockIdx.x, axes, samples, info, st_sc, st_xy, dyn_lds);
+}
+
+// Crop the cloud to the local costmap tile and count points per cell; the LAST
+// binning workgroup to finish (device-scope ticket) scans the counters, so binning is
+// two launches, not three.  Also resets the argmin key / capacity flag of the tick.
+// Workgroups [k.bin_blocks, gridDim.x) of the same launch run the body-frame rollout:
+// a cloud of ~10^4 points keeps only ~10 binning workgroups busy, the rollout fills
+// the rest of the chip for free and needs no cross-stream dependency.
+__global__ __launch_bounds__(kBinThreads) void k_bin_count(DevTick k, const float4* __restrict__ cloud,
+                                                   uint32_t* __restrict__ cell_count,
+                                                   uint32_t* __restrict__ cell_start,
+                                                   uint2* __restrict__ pt_slot, uint32_t* __restrict__ ticket,
+                                                   int64_t* __restrict__ best_key,
+                                                   uint32_t* __restrict__ overflow, const float* __restrict__ axes,
+                                                   const float4* __restrict__ samples, TrajInfo* __restrict__ info,
+                                                   double2* __restrict__ st_sc, float2* __restrict__ st_xy) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  if ((int)blockIdx.x >= k.bin_blocks) {
+    rollout_block<kBinThreads>(k, (int)blockIdx.x - k.bin_blocks, axes, samples, info, st_sc, st_xy, dyn_lds);
+    return;
+  }
+  __shared__ uint32_t wave_sum[16];
+  __shared__ uint32_t carry_s;
+  __shared__ uint32_t is_last;
+  const int stride = k.bin_blocks * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k.n_points; i += stride) {
+    const float4 p = cloud[i];
+    uint2 slot = make_uint2(0xFFFFFFFFu, 0u);
+    const bool in = p.x >= k.rmin[0] && p.x <= k.rmax[0] && p.y >= k.rmin[1] && p.y <= k.rmax[1] &&
+                    p.z >= k.rmin[2] && p.z <= k.rmax[2];
+    if (in) {
+      const int c = cell_of(k, p.x, p.y, p.z);
+      slot.x = (uint32_t)c;
+      slot.y = atomicAdd(&cell_count[c], 1u);
+    }
+    pt_slot[i] = slot;
+  }
+  // Ticket.  The only data handed to the last workgroup are the cell counters, and
+  // those are touched exclusively by device-scope atomics (returned => performed)
+  // and read back with device-scope atomic loads, so no cache write-back /
+  // invalidate is needed: every wave drains its atomics, barrier, one relaxed
+  // device-scope add per workgroup.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = (t == (uint32_t)k.bin_blocks - 1) ? 1u : 0u;
+    if (is_last) {
+      *ticket = 0;            // next tick
+      *best_key = kKeyNone;
+      *overflow = 0;
+    }
+  }
+  __syncthreads();
+  if (is_last) scan_cells(k, cell_count, cell_start, wave_sum, &carry_s);
 }
 
 // ---------------------------------------------------------------------------
@@ -330,6 +523,8 @@ struct TrajHead {     // per-trajectory header in LDS
   double pp_dist;     // PurePursuitModel: |translation| of the pose difference
   double pp_yaw;      // PurePursuitModel: folded yaw of the pose difference
   double stick_sum;   // StickPathModel: sum of the per-step 1-NN distances
+  int li;             // local trajectory index (row of the k_rollout state arrays)
+  int pad2;
 };
 
 // OBB record: [0..2] centre, [3..11] axes, [12..14] half extents, [15] cx0|cx1, [16] cy0|cy1,
@@ -353,15 +548,11 @@ __host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m
   b += sizeof(TrajHead) * (size_t)tile;
   b = (b + 15) & ~(size_t)15;
   b += 16 * (size_t)(m > 0 ? m : 1);                 // plan
-  b += 8 * (size_t)tile * S1;                        // xy
   b += 4 * (size_t)tile * S1;                        // dist
   b += 4 * (size_t)rec_words * Q;                    // OBB records
   b += 4 * (size_t)tab_entries;                      // costmap row-run index (cell_start slice), 0 = not staged
   b = (b + 15) & ~(size_t)15;
-  // union: {sc, inc, th} live in phases A..D1, {pref, seg_p, seg_len} in D2..D3
-  const size_t u1 = (16 + 16 + 4) * (size_t)tile * S1;
-  const size_t u2 = 4 * (Q * (size_t)rows_cap + 1) + 8 * (Q * (size_t)rows_cap);
-  b += (u1 > u2 ? u1 : u2) + 16;
+  b += 4 * (Q * (size_t)rows_cap + 1) + 8 * (Q * (size_t)rows_cap) + 16;   // pref, seg_p, seg_len
   b += 64;                                           // scan scratch
   return (b + 15) & ~(size_t)15;
 }
@@ -413,7 +604,7 @@ __device__ __forceinline__ void pose_translation(const DevTick& k, float2 bxy, d
 
 template <int kScoreThreads>
 __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
-    DevTick k, const float* __restrict__ axes, const float4* __restrict__ samples,
+    DevTick k, const TrajInfo* __restrict__ info, const double2* __restrict__ st_sc, const float2* __restrict__ st_xy,
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
     const float4* __restrict__ sorted, double* __restrict__ costs, int32_t* __restrict__ steps_out,
     float4* __restrict__ samples_out, int64_t* __restrict__ best_key, uint32_t* __restrict__ overflow,
@@ -423,7 +614,6 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   const int tile = k.tile;
   const int S1 = k.max_steps + 1;
   const int Qcap = tile * k.max_steps;
-  const bool omni = (k.kind == DDDMR_THEORY_OMNI_SIMPLE);
   const bool need_box = k.want_collision != 0, need_mm = k.want_minmax != 0;
   const int rec_words = rec_words_of(k.rec_pose != 0, need_mm);
   const int mm_ofs = kRecBase + (k.rec_pose ? 3 : 0);
@@ -433,8 +623,6 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   ofs = (ofs + 15) & ~(size_t)15;
   float4* plan = reinterpret_cast<float4*>(lds_raw + ofs);
   ofs += 16 * (size_t)(k.m > 0 ? k.m : 1);
-  float2* xy = reinterpret_cast<float2*>(lds_raw + ofs);
-  ofs += 8 * (size_t)tile * S1;
   float* dist = reinterpret_cast<float*>(lds_raw + ofs);
   ofs += 4 * (size_t)tile * S1;
   float* rec = reinterpret_cast<float*>(lds_raw + ofs);
@@ -442,19 +630,11 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   uint32_t* tab = reinterpret_cast<uint32_t*>(lds_raw + ofs);
   ofs += 4 * (size_t)k.tab_entries;
   ofs = (ofs + 15) & ~(size_t)15;
-  // union region: rollout scratch (phases A..D1) / collision segments (phases D2..D3)
-  const size_t uofs = ofs;
-  double2* sc = reinterpret_cast<double2*>(lds_raw + uofs);
-  double2* inc = sc + (size_t)tile * S1;                      // body-frame position increments per step
-  float* th = reinterpret_cast<float*>(inc + (size_t)tile * S1);
-  uint32_t* pref = reinterpret_cast<uint32_t*>(lds_raw + uofs);
+  // collision segments (phases D2..D3)
+  uint32_t* pref = reinterpret_cast<uint32_t*>(lds_raw + ofs);
   uint32_t* seg_p = pref + ((size_t)Qcap * k.rows_cap + 1);
   uint32_t* seg_len = seg_p + (size_t)Qcap * k.rows_cap;
-  {
-    const size_t u1 = (16 + 16 + 4) * (size_t)tile * S1;
-    const size_t u2 = 4 * ((size_t)Qcap * k.rows_cap + 1) + 8 * ((size_t)Qcap * k.rows_cap);
-    ofs += (u1 > u2 ? u1 : u2) + 16;
-  }
+  ofs += 4 * ((size_t)Qcap * k.rows_cap + 1) + 8 * ((size_t)Qcap * k.rows_cap) + 16;
   ofs = (ofs + 7) & ~(size_t)7;
   unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(lds_raw + ofs);
 
@@ -477,85 +657,31 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   // ---- stage the prune plan (float xyz, model_shared_data.h:83-91) ----
   for (int i = tid; i < k.m; i += kScoreThreads) plan[i] = plan_xyz[i];
 
-  // ---- phase A: sample, generation gates, step count, theta recurrence ----
+  // ---- phase A: trajectory headers from k_rollout ----
   if (tid < nt) {
     const int li = tb + tid * n_tiles;
-    const int gi = k.begin + li;
-    float vx, vy, w;
-    if (k.list_mode) {
-      const float4 s = samples[gi];
-      vx = s.x; vy = s.y; w = s.z;
-    } else {
-      const int ith = gi % k.nth;
-      const int r = gi / k.nth;
-      const int iy = r % k.ny;
-      const int ix = r / k.ny;
-      if (k.axes_inline) {
-        vx = k.axes_inl[ix];
-        vy = k.axes_inl[k.ay_ofs + iy];
-        w = k.axes_inl[k.ath_ofs + ith];
-      } else {
-        vx = axes[ix];
-        vy = axes[k.ay_ofs + iy];
-        w = axes[k.ath_ofs + ith];
-      }
-    }
-    const double eps = 1e-4;
-    bool ok = true;
-    double vmag, sim_time = k.sim_time;
-    if (k.kind == DDDMR_THEORY_DD_SIMPLE) {
-      // dd_simple_trajectory_generator_theory.cpp:364-371
-      vmag = fabs((double)vx);
-      if ((k.min_vel_x >= 0 && vmag + eps < k.min_vel_x) &&
-          (k.min_vel_theta >= 0 && fabs((double)w) + eps < k.min_vel_theta)) ok = false;
-      if (k.max_vel_x >= 0 && vmag - eps > k.max_vel_x) ok = false;
-    } else if (omni) {
-      // omni_simple_trajectory_generator_theory.cpp:387-411
-      vmag = hypot((double)vx, (double)vy);
-      if ((k.min_vel_trans >= 0 && vmag + eps < k.min_vel_trans) &&
-          (k.min_vel_theta >= 0 && fabs((double)w) + eps < k.min_vel_theta)) ok = false;
-      if (k.max_vel_trans >= 0 && vmag - eps > k.max_vel_trans) ok = false;
-      if (k.allowed_max > 0.0 && vmag - eps > k.allowed_max) ok = false;
-    } else {
-      // dd_rotate_inplace_theory.cpp:337: one full turn
-      vmag = fabs((double)vx);
-      sim_time = 6.28 / fabs((double)w);
-    }
-    int ns = 0;
-    if (ok) {
-      if (k.fixed_steps > 0) {
-        ns = k.fixed_steps;
-      } else {
-        const double sd = vmag * sim_time;
-        const double sa = fabs((double)w) * sim_time;
-        ns = (int)ceil(fmax(sd / k.sim_gran, sa / k.ang_gran));
-      }
-      if (ns > k.max_steps) {       // capacity error, reported to the host
-        atomicOr(overflow, 1u);
-        ns = 0;
-      }
-    }
-    const double dt = ns > 0 ? sim_time / (double)ns : 0.0;
+    const TrajInfo ti = info[li];
+    if (ti.over) atomicOr(overflow, 1u);
     TrajHead h;
-    h.vx = vx; h.vy = vy; h.w = w;
-    h.steps = ns;
-    h.dt = dt;
+    h.vx = ti.vx; h.vy = ti.vy; h.w = ti.w;
+    h.steps = ti.steps;
+    h.dt = ti.dt;
     h.pair_base = 0;
     h.hit_box = 0; h.hit_mm = 0; h.pad = 0;
     h.pp_dist = 0.0; h.pp_yaw = 0.0; h.stick_sum = 0.0;
+    h.li = li;
     head[tid] = h;
-    // theta_{k+1} = float(theta_k + w*dt)   (computeNewPositions, :457-464)
-    float* row = th + (size_t)tid * S1;
-    float a = 0.f;
-    row[0] = 0.f;
-    const double wdt = (double)w * dt;
-    for (int s = 1; s <= ns; ++s) {
-      a = (float)((double)a + wdt);
-      row[s] = a;
+  }
+  // the costmap's row-run index is staged meanwhile (independent loads)
+  const int tab_n = k.tab_entries;          // (gnx+1)*gny, or 0 when the index does not fit
+  const bool tab_staged = tab_n > 0;
+  if (tab_staged && k.n_points >= 5 && (need_box || need_mm)) {
+    for (int i = tid; i < tab_n; i += kScoreThreads) {
+      const int cy = i / (k.gnx + 1), cx = i - cy * (k.gnx + 1);
+      tab[i] = cell_start[(cy * k.gnx + cx) * k.gnz];
     }
   }
   __syncthreads();
-
   DDDMR_STAMP(1);   // end of phase A
   // pair offsets (tile <= 16: serial prefix by one lane)
   if (tid == 0) {
@@ -565,66 +691,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       acc += head[j].steps;
     }
   }
-
-  // ---- phase B: double sin/cos of every theta_k (k = 0..steps), all lanes ----
-  // theta_k feeds the next position update (cos/sin of the float state) and the
-  // pose's AngleAxisd(theta) rotation (dd_simple...cpp:416); the omni theory also
-  // needs cos/sin(M_PI_2 + theta) in double (omni_simple...cpp:501-502).  The
-  // body-frame position increment of step k, (v cos, v sin)(theta_k) * dt, only
-  // depends on theta_k, so it is formed here too and phase C is a bare running sum.
-  // The costmap's row-run index is staged meanwhile (independent loads).
-  const int tab_n = k.tab_entries;          // (gnx+1)*gny, or 0 when the index does not fit
-  const bool tab_staged = tab_n > 0;
-  if (tab_staged && k.n_points >= 5 && (need_box || need_mm)) {
-    for (int i = tid; i < tab_n; i += kScoreThreads) {
-      const int cy = i / (k.gnx + 1), cx = i - cy * (k.gnx + 1);
-      tab[i] = cell_start[(cy * k.gnx + cx) * k.gnz];
-    }
-  }
-  for (int idx = tid; idx < nt * S1; idx += kScoreThreads) {
-    const int j = idx / S1, s = idx - j * S1;
-    const TrajHead& h = head[j];
-    if (s <= h.steps) {
-      const double a = (double)th[(size_t)j * S1 + s];
-      double sn, cs;
-      sincos(a, &sn, &cs);
-      sc[(size_t)j * S1 + s] = make_double2(cs, sn);
-      const float cf = (float)cs, sf = (float)sn;      // cos/sin(float) overloads
-      double ix = (double)fmul(h.vx, cf), iy = (double)fmul(h.vx, sf);
-      if (omni) {
-        double s2, c2;
-        sincos(M_PI_2 + a, &s2, &c2);
-        ix += (double)h.vy * c2;
-        iy += (double)h.vy * s2;
-      }
-      inc[(size_t)j * S1 + s] = make_double2(ix * h.dt, iy * h.dt);
-    }
-  }
   __syncthreads();
-
-  DDDMR_STAMP(2);   // end of phase B
-  // ---- phase C: x,y recurrence in the body frame: p = float(double(p) + inc) ----
-  if (tid < nt) {
-    const int ns = head[tid].steps;
-    const double2* ir = inc + (size_t)tid * S1;
-    float2* xr = xy + (size_t)tid * S1;
-    float px = 0.f, py = 0.f;
-    int s = 0;
-    for (; s + 4 <= ns; s += 4) {
-      const double2 i0 = ir[s], i1 = ir[s + 1], i2 = ir[s + 2], i3 = ir[s + 3];
-      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); xr[s] = make_float2(px, py);
-      px = (float)((double)px + i1.x); py = (float)((double)py + i1.y); xr[s + 1] = make_float2(px, py);
-      px = (float)((double)px + i2.x); py = (float)((double)py + i2.y); xr[s + 2] = make_float2(px, py);
-      px = (float)((double)px + i3.x); py = (float)((double)py + i3.y); xr[s + 3] = make_float2(px, py);
-    }
-    for (; s < ns; ++s) {
-      const double2 i0 = ir[s];
-      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); xr[s] = make_float2(px, py);
-    }
-  }
-  __syncthreads();
-
-  DDDMR_STAMP(3);   // end of phase C
+  DDDMR_STAMP(2);
+  DDDMR_STAMP(3);
   // ---- phase D1: one (trajectory, step) pair per lane ----
   int total_pairs = 0;
   if (nt > 0) total_pairs = head[nt - 1].pair_base + head[nt - 1].steps;
@@ -634,8 +703,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     int j = 0;
     while (j + 1 < nt && head[j + 1].pair_base <= q) ++j;
     const int s = q - head[j].pair_base;
-    const double2 cs = sc[(size_t)j * S1 + s + 1];   // pose after the step
-    const float2 bxy = xy[(size_t)j * S1 + s];
+    const size_t so = (size_t)head[j].li * k.max_steps + s;
+    const double2 cs = st_sc[so];                    // heading after the step
+    const float2 bxy = st_xy[so];                    // body-frame position after the step
     const double c = cs.x, sn = cs.y;
     // trans_gbl2traj = pos_af3 * [Rz(theta), (x, y, 0)]
     double L[9], T[3];
@@ -912,7 +982,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     int j = 0;
     while (j + 1 < nt && head[j + 1].pad <= q2) ++j;      // (dead trajectories have empty ranges)
     const int s = q2 - head[j].pad;
-    const float2 bxy = xy[(size_t)j * S1 + s];
+    const float2 bxy = st_xy[(size_t)head[j].li * k.max_steps + s];
     double T[3];
     pose_translation(k, bxy, T);
     const float px = (float)T[0], py = (float)T[1], pz = (float)T[2];
