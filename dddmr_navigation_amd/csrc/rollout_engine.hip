@@ -177,10 +177,12 @@ struct dddmr_rollout_ctx {
   uint32_t* overflow = nullptr;
   DevResult* result_dev = nullptr;   // device alias of result_host (host-mapped)
   uint32_t* tickets = nullptr;       // [0] binning ticket, [1] scoring ticket
-  OrderState* order = nullptr;       // launch-order feedback (device)
-  uint32_t* perm[2] = {nullptr, nullptr};
-  int order_tiles = -1, order_theory = -1, order_nlocal = -1;
-  uint32_t order_seq = 0;
+  // load feedback (device): per-trajectory load of the last tick, tile assignment of this one
+  uint32_t* traj_load = nullptr;
+  uint32_t* assign = nullptr;
+  int load_theory = -1, load_nlocal = -1;   // what traj_load describes
+  bool no_assign = false;
+  bool gnz_one = false;
   double* poses_dev = nullptr;
   // perception feed scratch
   PerceptionScratch feed{};
@@ -308,6 +310,10 @@ extern "C" {
 int dddmr_rollout_diag_stamps(unsigned long long* out, size_t n_words) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), n_words * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
+// ... and of the last k_bin_count launch (binning, assignment and rollout workgroups)
+int dddmr_rollout_diag_rstamps(unsigned long long* out, size_t n_words) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rstamps), n_words * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 #endif
 
 const char* dddmr_rollout_version(void) { return "dddmr-rollout-mi355x 0.1 (gfx950)"; }
@@ -342,7 +348,7 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   }
   void* dev[] = {ctx->pt_slot, ctx->sorted, ctx->cell_count, ctx->cell_start, ctx->axes_dev,
                  ctx->samples_dev, ctx->plan_dev, ctx->costs, ctx->steps, ctx->samples_out,
-                 ctx->best_key, ctx->overflow, ctx->tickets, ctx->poses_dev, ctx->order, ctx->perm[0], ctx->perm[1]};
+                 ctx->best_key, ctx->overflow, ctx->tickets, ctx->poses_dev, ctx->traj_load, ctx->assign};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   perception_free(ctx->feed);
@@ -428,10 +434,11 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMalloc(&ctx->samples_out, N * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&ctx->best_key, sizeof(int64_t)));
     HIPCHK(ctx, hipMalloc(&ctx->overflow, sizeof(uint32_t)));
-    HIPCHK(ctx, hipMalloc(&ctx->order, sizeof(OrderState)));
-    HIPCHK(ctx, hipMemset(ctx->order, 0, sizeof(OrderState)));
-    HIPCHK(ctx, hipMalloc(&ctx->perm[0], N * sizeof(uint32_t)));
-    HIPCHK(ctx, hipMalloc(&ctx->perm[1], N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->traj_load, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(ctx->traj_load, 0, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->assign, N * sizeof(uint32_t)));
+    ctx->no_assign = std::getenv("DDDMR_NO_ASSIGN") != nullptr;
+    ctx->gnz_one = std::getenv("DDDMR_GNZ_ONE") != nullptr;
     HIPCHK(ctx, hipMalloc(&ctx->tickets, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(ctx->tickets, 0, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->poses_dev, (size_t)cfg->max_steps * 7 * sizeof(double)));
@@ -710,7 +717,9 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   for (;;) {
     k.gnx = std::max(1, (int)std::ceil((k.rmax[0] - k.rmin[0]) / cell));
     k.gny = std::max(1, (int)std::ceil((k.rmax[1] - k.rmin[1]) / cell));
-    k.gnz = std::max(1, (int)std::ceil((k.rmax[2] - k.rmin[2]) / cell));
+    // Candidate runs always take every z of a row, but one cell column per (x, y) makes the
+    // counting atomics of wall points collide (measured: k_bin_count 13 -> 17 us); keep z.
+    k.gnz = ctx->gnz_one ? 1 : std::max(1, (int)std::ceil((k.rmax[2] - k.rmin[2]) / cell));
     const uint64_t nc = (uint64_t)k.gnx * k.gny * k.gnz;
     if (nc <= kCapCells && k.gnx < 32000 && k.gny < 32000) { k.n_cells = (int)nc; break; }
     cell *= 1.5f;
@@ -793,7 +802,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
       HIPCHK(ctx, hipDeviceSynchronize());
       if (ctx->st_sc) (void)hipFree(ctx->st_sc);
       if (ctx->st_xy) (void)hipFree(ctx->st_xy);
-      ctx->st_sc = nullptr; ctx->st_xy = nullptr; ctx->st_cap = 0;
+          ctx->st_sc = nullptr; ctx->st_xy = nullptr; ctx->st_cap = 0;
       const size_t cap = need + need / 4 + 1024;
       HIPCHK(ctx, hipMalloc(&ctx->st_sc, cap * sizeof(double2)));
       HIPCHK(ctx, hipMalloc(&ctx->st_xy, cap * sizeof(float2)));
@@ -818,10 +827,22 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   const int roll_blocks = k.n_local > 0 ? (k.n_local + k.rt - 1) / k.rt : 0;
   const size_t roll_lds = k.n_local > 0 ? rollout_lds_bytes(k.rt, s_tick) : 0;
   k.bin_blocks = cnt_blocks;
+  k.roll_blocks = roll_blocks;
+  // Load feedback: valid when the previous tick scored the same shard of the same theory
+  // (its loads are indexed by local trajectory).  Otherwise this tick deals strided.
+  const int theory_id = (int)(th - ctx->theories.data());
+  k.n_tiles = k.n_local > 0 ? (k.n_local + tile - 1) / tile : 0;
+  k.assign_groups = std::max(1, (k.n_local + kAssignPer * kBinThreads - 1) / (kAssignPer * kBinThreads));
+  k.use_assign = (!ctx->no_assign && k.n_tiles > 1 && k.n_local <= kAssignMax && ctx->load_theory == theory_id &&
+                  ctx->load_nlocal == k.n_local) ? 1 : 0;
+  if (k.use_assign) k.n_tiles = (k.n_tiles + k.assign_groups - 1) / k.assign_groups * k.assign_groups;
+  ctx->load_theory = theory_id;
+  ctx->load_nlocal = k.n_local;
   if (k.n_points > 0) {
-    hipLaunchKernelGGL(k_bin_count, dim3(cnt_blocks + roll_blocks), dim3(kBinThreads), roll_lds, ctx->stream, k,
-                       ctx->cloud_dev[cidx], ctx->cell_count, ctx->cell_start, ctx->pt_slot, ctx->tickets, ctx->best_key,
-                       ctx->overflow, ctx->axes_dev, ctx->samples_dev, ctx->traj_info, ctx->st_sc, ctx->st_xy);
+    hipLaunchKernelGGL(k_bin_count, dim3(cnt_blocks + roll_blocks + (k.use_assign ? k.assign_groups : 0)), dim3(kBinThreads), roll_lds, ctx->stream,
+                       k, ctx->cloud_dev[cidx], ctx->cell_count, ctx->cell_start, ctx->pt_slot, ctx->tickets,
+                       ctx->best_key, ctx->overflow, ctx->axes_dev, ctx->samples_dev, ctx->traj_info, ctx->st_sc,
+                       ctx->st_xy, ctx->traj_load, ctx->assign);
     hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks), dim3(256), 0, ctx->stream, k, ctx->cloud_dev[cidx],
                        ctx->pt_slot, ctx->cell_start, ctx->sorted);
   } else {
@@ -830,29 +851,22 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     if (roll_blocks > 0)
       hipLaunchKernelGGL(k_rollout, dim3(roll_blocks), dim3(256), roll_lds, ctx->stream, k, ctx->axes_dev,
                          ctx->samples_dev, ctx->traj_info, ctx->st_sc, ctx->st_xy);
+    if (k.use_assign)
+      hipLaunchKernelGGL(k_assign, dim3(k.assign_groups), dim3(kBinThreads), 0, ctx->stream, k, ctx->traj_load, ctx->assign);
   }
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
   if (k.n_local > 0) {
-    const int wgs = (k.n_local + tile - 1) / tile;
-    // Launch-order feedback only carries over between ticks of the same launch shape
-    // (and consecutive sequence numbers: the books are double-buffered by parity).
-    const int theory_id = (int)(th - ctx->theories.data());
-    const bool same = ctx->order_tiles == wgs && ctx->order_theory == theory_id && ctx->order_nlocal == k.n_local &&
-                      ctx->order_seq + 1 == k.seq;
-    if (!same) HIPCHK(ctx, hipMemsetAsync(ctx->order, 0, sizeof(OrderState), ctx->stream));
-    k.use_perm = (wgs > 256 && !std::getenv("DDDMR_NO_PERM")) ? 1 : 0;
-    if (k.use_perm && std::getenv("DDDMR_PERM_IDENT")) k.use_perm = 2;   // experiment: keep the books, launch in index order
-    ctx->order_tiles = wgs; ctx->order_theory = theory_id; ctx->order_nlocal = k.n_local; ctx->order_seq = k.seq;
+    const int wgs = k.n_tiles;
     if (thr == 512)
       hipLaunchKernelGGL(k_score<512>, dim3(wgs), dim3(512), lds, ctx->stream, k, ctx->traj_info,
                          ctx->st_sc, ctx->st_xy, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
                          ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev,
-                         ctx->order, ctx->perm[0], ctx->perm[1]);
+                         ctx->assign, ctx->traj_load);
     else
       hipLaunchKernelGGL(k_score<256>, dim3(wgs), dim3(256), lds, ctx->stream, k, ctx->traj_info,
                          ctx->st_sc, ctx->st_xy, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
                          ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev,
-                         ctx->order, ctx->perm[0], ctx->perm[1]);
+                         ctx->assign, ctx->traj_load);
   } else {
     hipLaunchKernelGGL(k_empty_result, dim3(1), dim3(64), 0, ctx->stream, k, ctx->cell_start, ctx->result_dev);
   }

@@ -81,38 +81,25 @@ struct DevTick {
   // sample axes inline in the kernarg segment when they fit (no per-tick H2D copy):
   // x at [0,nx), y at [nx,nx+ny), theta at [nx+ny, nx+ny+nth)
   int axes_inline;
-  int use_perm;      // launch-order feedback is valid for this launch shape
+  int use_assign;    // 1: tiles take their trajectories from assign[] (load feedback), 0: strided
+  int n_tiles;       // k_score workgroups of this tick (a multiple of assign_groups)
+  int assign_groups; // assignment workgroups
   int rows_cap;      // cell rows one cuboid AABB can span with this tick's cell size (<= kRows)
   int rt;            // trajectories per rollout workgroup
-  int bin_blocks;    // binning workgroups of the k_bin_count launch (the rest roll out)
+  int bin_blocks;    // binning workgroups of the k_bin_count launch, followed by
+  int roll_blocks;   // the rollout workgroups and (use_assign) one assignment workgroup
   int rec_pose;      // OBB records carry the pose (some pair may need the 1 m radius test, or min-max critic)
   uint32_t seq;      // tick sequence number echoed into DevResult::seq
   float axes_inl[kInlineAxes];
 };
 
-// Launch-order feedback (device resident, double-buffered by tick parity): every
-// k_score workgroup files its tile under a load class; the next tick dispatches
-// the heaviest classes first so that the long workgroups start at once and the
-// tail of the launch is made of light ones.  Any order gives identical results.
-constexpr int kLoadClasses = 8;
-struct alignas(128) OrderBook {        // atomically updated while a launch runs: one 128-B line per counter kind
-  uint32_t cnt[kLoadClasses];          // tiles filed per class
-  uint32_t pad0[32 - kLoadClasses];
-  uint32_t sum;                        // total load (collision work items)
-  uint32_t pad1[31];
-  uint32_t bad;                        // a class region overflowed => perm is not a permutation
-  uint32_t pad2[31];
-};
-struct alignas(128) OrderPlan {        // read-only while a launch runs (written by the previous launch's last workgroup)
-  uint32_t base[kLoadClasses + 1];     // class regions of perm[]
-  uint32_t mean;                       // load per tile
-  uint32_t valid;
-  uint32_t pad[32 - kLoadClasses - 3];
-};
-struct OrderState {
-  OrderBook book[2];
-  OrderPlan plan[2];
-};
+// Load feedback: every tick k_score files what each trajectory cost it (collision
+// work items actually walked, path-critic work, pairs); the next tick's assignment
+// block (rides along with k_bin_count, like the rollout) deals the trajectories to
+// the tiles heaviest-first in snake order, so that all workgroups carry the same
+// load and the launch has no long tail.  Any assignment gives identical results.
+constexpr int kLoadClasses = 1024;
+constexpr int kAssignMax = 1 << 18;    // larger shards keep the strided assignment (64 groups of 4096)
 
 struct DevResult {    // written by the last k_score workgroup into host-mapped memory
   int64_t key;
@@ -260,6 +247,24 @@ __global__ __launch_bounds__(256) void k_bin_scatter(DevTick k, const float4* __
 // Output per (trajectory, step): body-frame x,y after the step (float2) and
 // cos/sin of the heading after the step (double2, the pose's AngleAxisd rotation).
 // ---------------------------------------------------------------------------
+#ifdef DDDMR_PHASE_STAMPS
+constexpr int kStampSlots = 10;
+__device__ unsigned long long g_stamps[16384 * kStampSlots];
+#define DDDMR_STAMP(i)                                                                         \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * kStampSlots + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+// rollout / assignment / binning workgroups of the k_bin_count launch: 8 slots per block
+__device__ unsigned long long g_rstamps[4096 * 8];
+#define DDDMR_RSTAMP(i)                                                                        \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) g_rstamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define DDDMR_STAMP(i) do { } while (0)
+#define DDDMR_RSTAMP(i) do { } while (0)
+#endif
+
 struct TrajInfo {      // per trajectory, 32 bytes
   float vx, vy, w;
   int steps;           // 0 = not generated
@@ -269,7 +274,7 @@ struct TrajInfo {      // per trajectory, 32 bytes
 };
 
 __host__ __device__ inline size_t rollout_lds_bytes(int rt, int max_steps) {
-  return (size_t)rt * (size_t)(max_steps + 1) * (4 + 16) + 16;
+  return (size_t)rt * (size_t)(max_steps + 1) * (4 + 16) + 16;   // theta + increment rows
 }
 
 template <int kThreads>
@@ -279,7 +284,7 @@ __device__ __forceinline__ void rollout_block(const DevTick& k, const int block,
                                               unsigned char* roll_lds) {
   const int S1 = k.max_steps + 1;
   const int rt = k.rt;
-  double2* inc = reinterpret_cast<double2*>(roll_lds);                  // [rt][S1]
+  double2* inc = reinterpret_cast<double2*>(roll_lds);                   // [rt][S1]
   float* th = reinterpret_cast<float*>(inc + (size_t)rt * S1);           // [rt][S1]
   __shared__ int steps_s[64];
   __shared__ float vel_s[64][3];
@@ -288,6 +293,7 @@ __device__ __forceinline__ void rollout_block(const DevTick& k, const int block,
   const int l0 = block * rt;                          // first local trajectory of this workgroup
   const int nt = min(rt, k.n_local - l0);
   const bool omni = (k.kind == DDDMR_THEORY_OMNI_SIMPLE);
+  DDDMR_RSTAMP(0);
 
   // ---- phase A ----
   if (tid < nt) {
@@ -370,15 +376,16 @@ __device__ __forceinline__ void rollout_block(const DevTick& k, const int block,
     }
   }
   __syncthreads();
+  DDDMR_RSTAMP(1);
 
   // ---- phase B ----
   for (int idx = tid; idx < nt * S1; idx += kThreads) {
     const int j = idx / S1, s = idx - j * S1;
     const int ns = steps_s[j];
     if (s <= ns) {
-      const double a = (double)th[(size_t)j * S1 + s];
+      const double ang = (double)th[idx];
       double sn, cs;
-      sincos(a, &sn, &cs);
+      sincos(ang, &sn, &cs);
       // heading after step s-1 = theta_s: the pose's rotation (dd_simple...cpp:416)
       if (s >= 1) st_sc[(size_t)(l0 + j) * k.max_steps + (s - 1)] = make_double2(cs, sn);
       if (s < ns) {
@@ -386,37 +393,143 @@ __device__ __forceinline__ void rollout_block(const DevTick& k, const int block,
         const float cf = (float)cs, sf = (float)sn;      // cos/sin(float) overloads
         double ix = (double)fmul(vx, cf), iy = (double)fmul(vx, sf);
         if (omni) {
-          // cos/sin(M_PI_2 + theta) in double (omni_simple...cpp:501-502)
-          double s2, c2;
-          sincos(M_PI_2 + a, &s2, &c2);
+          // cos/sin(M_PI_2 + theta) in double (omni_simple...cpp:501-502).  The argument
+          // the reference hands to libm is t = fl(fl(pi/2) + theta) = pi/2 + theta - e with
+          // e = (pi/2 - fl(pi/2)) + (rounding error of the sum, exact by Fast2Sum), so
+          // cos t = -sin(theta - e), sin t = cos(theta - e): first-order corrections of
+          // the values already at hand (|e| < 3e-16, the neglected term < 1e-31) instead
+          // of a second sincos -- the double sincos is what bounds this phase.
+          const double t = M_PI_2 + ang;
+          const double err = fabs(ang) <= M_PI_2 ? (M_PI_2 - t) + ang : (ang - t) + M_PI_2;   // (pi/2_fl + theta) - t
+          const double e = 6.123233995736766e-17 + err;
+          const double c2 = -sn + e * cs;
+          const double s2 = cs + e * sn;
           ix += (double)vy * c2;
           iy += (double)vy * s2;
         }
-        inc[(size_t)j * S1 + s] = make_double2(ix * dt_s[j], iy * dt_s[j]);
+        inc[idx] = make_double2(ix * dt_s[j], iy * dt_s[j]);
       }
     }
   }
   __syncthreads();
+  DDDMR_RSTAMP(2);
 
-  // ---- phase C ----
+  // ---- phase C ----  (x, y overwrite the consumed increment slots; a coalesced copy-out follows)
   if (tid < nt) {
     const int ns = steps_s[tid];
-    const double2* ir = inc + (size_t)tid * S1;
-    float2* xr = st_xy + (size_t)(l0 + tid) * k.max_steps;
+    double2* ir = inc + (size_t)tid * S1;
     float px = 0.f, py = 0.f;
     int s = 0;
     for (; s + 4 <= ns; s += 4) {
       const double2 i0 = ir[s], i1 = ir[s + 1], i2 = ir[s + 2], i3 = ir[s + 3];
-      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); xr[s] = make_float2(px, py);
-      px = (float)((double)px + i1.x); py = (float)((double)py + i1.y); xr[s + 1] = make_float2(px, py);
-      px = (float)((double)px + i2.x); py = (float)((double)py + i2.y); xr[s + 2] = make_float2(px, py);
-      px = (float)((double)px + i3.x); py = (float)((double)py + i3.y); xr[s + 3] = make_float2(px, py);
+      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); *reinterpret_cast<float2*>(ir + s) = make_float2(px, py);
+      px = (float)((double)px + i1.x); py = (float)((double)py + i1.y); *reinterpret_cast<float2*>(ir + s + 1) = make_float2(px, py);
+      px = (float)((double)px + i2.x); py = (float)((double)py + i2.y); *reinterpret_cast<float2*>(ir + s + 2) = make_float2(px, py);
+      px = (float)((double)px + i3.x); py = (float)((double)py + i3.y); *reinterpret_cast<float2*>(ir + s + 3) = make_float2(px, py);
     }
     for (; s < ns; ++s) {
       const double2 i0 = ir[s];
-      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); xr[s] = make_float2(px, py);
+      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); *reinterpret_cast<float2*>(ir + s) = make_float2(px, py);
     }
   }
+  __syncthreads();
+  for (int idx = tid; idx < nt * S1; idx += kThreads) {
+    const int j = idx / S1, s = idx - j * S1;
+    if (s < steps_s[j]) st_xy[(size_t)(l0 + j) * k.max_steps + s] = *reinterpret_cast<const float2*>(inc + idx);
+  }
+  DDDMR_RSTAMP(3);
+}
+
+// Assignment blocks: counting sort of the shard's trajectories by last tick's load,
+// heaviest first, then dealt to the tiles in snake order (rank r -> round r / tiles,
+// tile r % tiles, reversed in odd rounds).  Slot [round * n_tiles + tile] of assign[]
+// is what k_score reads.  Big shards are cut into k.assign_groups independent
+// groups, one workgroup each: group g owns the trajectories AND the tiles congruent
+// to g (n_tiles is a multiple of the group count), so every group deals a
+// representative sample of the shard to its own tiles.  Whatever the loads hold
+// (first tick: zeros), the result is a permutation.
+constexpr int kAssignPer = 4;          // trajectories per lane of an assignment block (held in registers)
+template <int kThreads>
+__device__ __forceinline__ void assign_block(const DevTick& k, const int grp, const uint32_t* __restrict__ load,
+                                             uint32_t* __restrict__ assign) {
+  __shared__ uint32_t hist[kLoadClasses];
+  __shared__ uint32_t wsum[kThreads / 64];
+  __shared__ uint32_t mx_s, mn_s;
+  static_assert(kLoadClasses == kThreads, "one class per lane in the scan");
+  const int tid = threadIdx.x;
+  const int G = k.assign_groups;
+  const int n = k.n_local, n_tiles = k.n_tiles, tl = n_tiles / G;
+  const int ng = (n - grp + G - 1) / G;              // trajectories (and slots) of this group
+  DDDMR_RSTAMP(0);
+  hist[tid] = 0;
+  if (tid == 0) { mx_s = 1; mn_s = 0xFFFFFFFFu; }
+  uint32_t v[kAssignPer];
+  uint32_t mx = 1, mn = 0xFFFFFFFFu;
+#pragma unroll
+  for (int e = 0; e < kAssignPer; ++e) {
+    const int m = tid + e * kThreads;
+    v[e] = m < ng ? load[grp + G * m] : 0u;
+    if (m < ng) { mx = max(mx, v[e]); mn = min(mn, v[e]); }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+    mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+  }
+  __syncthreads();
+  if ((tid & 63) == 0) { atomicMax(&mx_s, mx); atomicMin(&mn_s, mn); }
+  __syncthreads();
+  const int full_rounds = n / n_tiles;
+  if (mx_s <= mn_s) {
+    // all loads equal (e.g. no cloud): nothing to balance, deal in index order
+#pragma unroll
+    for (int e = 0; e < kAssignPer; ++e) {
+      const int m = tid + e * kThreads;
+      if (m < ng) {
+        const int round = m / tl, bl = m - round * tl;
+        assign[(size_t)round * n_tiles + grp + G * bl] = (uint32_t)(grp + G * m);
+      }
+    }
+    return;
+  }
+  const float scale = (float)(kLoadClasses - 1) / (float)mx_s;
+#pragma unroll
+  for (int e = 0; e < kAssignPer; ++e) {
+    const int m = tid + e * kThreads;
+    if (m < ng) atomicAdd(&hist[kLoadClasses - 1 - min(kLoadClasses - 1, (int)((float)v[e] * scale))], 1u);
+  }
+  __syncthreads();
+  // exclusive scan of the classes, one per lane
+  const uint32_t cnt = hist[tid];
+  uint32_t inc = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t up = __shfl_up(inc, o, 64);
+    if ((tid & 63) >= o) inc += up;
+  }
+  if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+  __syncthreads();
+  uint32_t base = inc - cnt;
+  for (int w = 0; w < (tid >> 6); ++w) base += wsum[w];
+  hist[tid] = base;
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < kAssignPer; ++e) {
+    const int m = tid + e * kThreads;
+    if (m < ng) {
+      const int c = kLoadClasses - 1 - min(kLoadClasses - 1, (int)((float)v[e] * scale));
+      const int r = (int)atomicAdd(&hist[c], 1u);
+      const int round = r / tl, pos = r - round * tl;
+      const int bl = ((round & 1) && round < full_rounds) ? tl - 1 - pos : pos;
+      assign[(size_t)round * n_tiles + grp + G * bl] = (uint32_t)(grp + G * m);
+    }
+  }
+  DDDMR_RSTAMP(3);
+}
+
+__global__ __launch_bounds__(kBinThreads) void k_assign(DevTick k, const uint32_t* __restrict__ load,
+                                                        uint32_t* __restrict__ assign) {
+  assign_block<kBinThreads>(k, (int)blockIdx.x, load, assign);
 }
 
 // Stand-alone launch (empty cloud: there is no k_bin_count to ride along with).
@@ -431,7 +544,8 @@ __global__ __launch_bounds__(256) void k_rollout(DevTick k, const float* __restr
 // Crop the cloud to the local costmap tile and count points per cell; the LAST
 // binning workgroup to finish (device-scope ticket) scans the counters, so binning is
 // two launches, not three.  Also resets the argmin key / capacity flag of the tick.
-// Workgroups [k.bin_blocks, gridDim.x) of the same launch run the body-frame rollout:
+// The workgroups after the k.bin_blocks binning ones run the tile assignment (a few)
+// and the body-frame rollout:
 // a cloud of ~10^4 points keeps only ~10 binning workgroups busy, the rollout fills
 // the rest of the chip for free and needs no cross-stream dependency.
 __global__ __launch_bounds__(kBinThreads) void k_bin_count(DevTick k, const float4* __restrict__ cloud,
@@ -441,16 +555,23 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(DevTick k, const floa
                                                    int64_t* __restrict__ best_key,
                                                    uint32_t* __restrict__ overflow, const float* __restrict__ axes,
                                                    const float4* __restrict__ samples, TrajInfo* __restrict__ info,
-                                                   double2* __restrict__ st_sc, float2* __restrict__ st_xy) {
+                                                   double2* __restrict__ st_sc, float2* __restrict__ st_xy,
+                                                   const uint32_t* __restrict__ load, uint32_t* __restrict__ assign) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
-  if ((int)blockIdx.x >= k.bin_blocks) {
-    rollout_block<kBinThreads>(k, (int)blockIdx.x - k.bin_blocks, axes, samples, info, st_sc, st_xy, dyn_lds);
+  const int n_assign = k.use_assign ? k.assign_groups : 0;
+  if ((int)blockIdx.x >= k.bin_blocks + n_assign) {
+    rollout_block<kBinThreads>(k, (int)blockIdx.x - k.bin_blocks - n_assign, axes, samples, info, st_sc, st_xy, dyn_lds);
+    return;
+  }
+  if ((int)blockIdx.x >= k.bin_blocks) {   // assignment blocks (only launched with use_assign)
+    assign_block<kBinThreads>(k, (int)blockIdx.x - k.bin_blocks, load, assign);
     return;
   }
   __shared__ uint32_t wave_sum[16];
   __shared__ uint32_t carry_s;
   __shared__ uint32_t is_last;
   const int stride = k.bin_blocks * blockDim.x;
+  DDDMR_RSTAMP(0);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k.n_points; i += stride) {
     const float4 p = cloud[i];
     uint2 slot = make_uint2(0xFFFFFFFFu, 0u);
@@ -480,7 +601,9 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(DevTick k, const floa
     }
   }
   __syncthreads();
+  DDDMR_RSTAMP(1);
   if (is_last) scan_cells(k, cell_count, cell_start, wave_sum, &carry_s);
+  DDDMR_RSTAMP(3);
 }
 
 // ---------------------------------------------------------------------------
@@ -501,16 +624,6 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(DevTick k, const floa
 // ---------------------------------------------------------------------------
 // Diagnostic build only (make diag): per-workgroup phase timestamps, written to a
 // buffer nothing else reads (cdna_hip_programming.md 7, In-kernel stamps).
-#ifdef DDDMR_PHASE_STAMPS
-constexpr int kStampSlots = 10;
-__device__ unsigned long long g_stamps[16384 * kStampSlots];
-#define DDDMR_STAMP(i)                                                                         \
-  do {                                                                                         \
-    if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * kStampSlots + (i)] = __builtin_amdgcn_s_memtime(); \
-  } while (0)
-#else
-#define DDDMR_STAMP(i) do { } while (0)
-#endif
 
 struct TrajHead {     // per-trajectory header in LDS
   float vx, vy, w;
@@ -608,8 +721,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
     const float4* __restrict__ sorted, double* __restrict__ costs, int32_t* __restrict__ steps_out,
     float4* __restrict__ samples_out, int64_t* __restrict__ best_key, uint32_t* __restrict__ overflow,
-    uint32_t* __restrict__ ticket, DevResult* __restrict__ result, OrderState* __restrict__ order,
-    uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1) {
+    uint32_t* __restrict__ ticket, DevResult* __restrict__ result, const uint32_t* __restrict__ assign,
+    uint32_t* __restrict__ traj_load) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tile = k.tile;
   const int S1 = k.max_steps + 1;
@@ -641,16 +754,13 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   __shared__ int alive_pairs_s;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
-  // Tile b scores local trajectories b, b + n_tiles, b + 2 n_tiles, ...: neighbours
-  // in sample order head the same way and would make whole tiles cheap (open
-  // space) or expensive (along a wall); striding mixes them so that the
-  // workgroups carry similar amounts of collision work.
+  // Tile b scores the trajectories in slots b, b + n_tiles, b + 2 n_tiles, ... of the
+  // assignment (load feedback, see assign_block) or, without one, the local
+  // trajectories of those indices: neighbours in sample order head the same way and
+  // would make whole tiles cheap (open space) or expensive (along a wall); striding
+  // mixes them.
   const int n_tiles = gridDim.x;
-  const int par = (int)(k.seq & 1u), prv = par ^ 1;
-  uint32_t* perm_cur = par ? perm1 : perm0;        // filled by this tick
-  const uint32_t* perm_prv = par ? perm0 : perm1;  // filled by the previous tick
-  // tile taken by this workgroup: heaviest-first order measured by the previous tick
-  const int tb = (k.use_perm == 1 && order->plan[prv].valid) ? (int)perm_prv[blockIdx.x] : (int)blockIdx.x;
+  const int tb = (int)blockIdx.x;
   const int nt = (k.n_local - tb + n_tiles - 1) / n_tiles;   // <= tile
 
   DDDMR_STAMP(0);
@@ -659,7 +769,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
 
   // ---- phase A: trajectory headers from k_rollout ----
   if (tid < nt) {
-    const int li = tb + tid * n_tiles;
+    const int slot = tb + tid * n_tiles;
+    const int li = k.use_assign ? (int)assign[slot] : slot;
     const TrajInfo ti = info[li];
     if (ti.over) atomicOr(overflow, 1u);
     TrajHead h;
@@ -800,19 +911,6 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   __syncthreads();
 
   DDDMR_STAMP(4);   // end of phase D1
-  uint32_t ob_pos = 0;     // this tile's slot inside its load class (launch-order feedback)
-  int ob_cls = kLoadClasses - 1;
-  auto file_order = [&](uint32_t items) {
-    // file this tile under its load class (regions sized by the previous tick's histogram);
-    // issued as early as the load is known so the atomics' latency hides behind later phases
-    const uint32_t mean = __hip_atomic_load(&order->plan[prv].mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (mean > 0) {
-      const float x = (float)items / (float)mean;
-      ob_cls = x >= 3.0f ? 0 : x >= 2.5f ? 1 : x >= 2.0f ? 2 : x >= 1.6f ? 3 : x >= 1.3f ? 4 : x >= 1.0f ? 5 : x >= 0.5f ? 6 : 7;
-    }
-    ob_pos = __hip_atomic_fetch_add(&order->book[par].cnt[ob_cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&order->book[par].sum, items, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
   if (do_coll && total_pairs > 0) {
     // ---- phase D2: row segments per pair -----------------------------------
     // z is the fastest cell axis, then x: the cells [cx0..cx1] x all z of one y-row
@@ -891,7 +989,6 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     const int nseg = (int)(carry >> 32);
     const uint32_t total = (uint32_t)carry;
     if (tid == 0) pref[nseg] = total;
-    if (tid == 0 && k.use_perm) file_order(total);
     __syncthreads();
 
     DDDMR_STAMP(5);   // end of phase D2
@@ -920,6 +1017,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         const bool hb = !need_box || head[j].hit_box != 0;
         const bool hm = !need_mm || head[j].hit_mm != 0;
         if (hb && hm) continue;                     // trajectory already decided
+        atomicAdd(&head[j].pad, 1);                 // load feedback: items walked for this trajectory
         const uint32_t off = (it - pref[sg]) * kItem;
         const uint32_t p0 = seg_p[sg] + off;
         const uint32_t n = min((uint32_t)kItem, (sl_len >> 12) - off);
@@ -960,7 +1058,6 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   __syncthreads();
 
   DDDMR_STAMP(6);   // end of phase D3
-  if (tid == 0 && k.use_perm && !(do_coll && total_pairs > 0)) file_order(0u);
   // ---- phase P: path critics, only for trajectories that did not collide ----
   // A collision verdict makes the trajectory's cost -1 whatever the path critics
   // would return (first negative return wins and StickPath / TowardGlobalPlan never
@@ -1024,7 +1121,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   int64_t key = kKeyNone;
   if (tid < nt) {
     const TrajHead h = head[tid];
-    const int li = tb + tid * n_tiles;
+    const int li = head[tid].li;
     const int gi = k.begin + li;
     double cost = DDDMR_COST_NOT_GENERATED;
     if (h.steps > 0) {
@@ -1081,6 +1178,10 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     __hip_atomic_store(so + 2, h.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     so[3] = 0.f;
     steps_out[li] = h.steps;
+    // what this trajectory cost (in collision work items): the walk, the path critics'
+    // 1-NN searches when it got that far, and the per-pair phases
+    const bool collided = (need_box && h.hit_box) || (need_mm && h.hit_mm);
+    traj_load[li] = (uint32_t)h.pad + (uint32_t)h.steps * (2u + (collided ? 0u : (uint32_t)((k.m + 15) >> 4)));
   }
   // wave-0 shuffle min-reduction of the packed keys, one atomic per workgroup
   if (tid < 64) {
@@ -1097,34 +1198,12 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   // read with device-scope loads; waves drain their stores, barrier, one relaxed
   // device-scope ticket.  The workgroup drawing the last ticket writes the result
   // straight into host-mapped memory (no finalize launch, no D2H copy).
-  if (tid == 0 && k.use_perm) {
-    // the order-book slot was drawn right after D2 (its latency hid behind the walk)
-    const uint32_t b0 = order->plan[prv].base[ob_cls], b1 = order->plan[prv].base[ob_cls + 1];
-    if (b0 + ob_pos < b1) __hip_atomic_store(&perm_cur[b0 + ob_pos], (uint32_t)tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else __hip_atomic_store(&order->book[par].bad, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
     const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t == gridDim.x - 1) {
       *ticket = 0;
-      if (k.use_perm) {
-        // close this tick's order book: valid iff every class filled exactly its region
-        uint32_t acc = 0, ok = __hip_atomic_load(&order->book[par].bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
-        for (int c = 0; c < kLoadClasses; ++c) {
-          const uint32_t n = __hip_atomic_load(&order->book[par].cnt[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          ok = ok && (n == order->plan[prv].base[c + 1] - order->plan[prv].base[c]);
-          order->plan[par].base[c] = acc;
-          acc += n;
-          order->book[prv].cnt[c] = 0;                 // the next tick files into the other parity
-        }
-        order->plan[par].base[kLoadClasses] = acc;
-        order->plan[par].valid = ok ? 1u : 0u;
-        order->plan[par].mean = __hip_atomic_load(&order->book[par].sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / (uint32_t)n_tiles;
-        order->book[prv].sum = 0;
-        order->book[prv].bad = 0;
-      }
       DevResult r;
       r.key = __hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       r.index = key_index(r.key);
