@@ -18,6 +18,10 @@
 
 #include <cstring>
 
+// The reference is an x86-64 build without FMA contraction: every multiply and add below
+// rounds separately, in float and in double (hipcc's default would fuse them).
+#pragma clang fp contract(off)
+
 namespace dddmr {
 
 struct FeedParams {

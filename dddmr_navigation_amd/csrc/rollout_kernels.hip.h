@@ -24,8 +24,15 @@
 
 #include "../../include/dddmr_rollout.h"
 
+// The reference is an x86-64 build without FMA contraction: every multiply and add below
+// rounds separately, in float and in double (hipcc's default would fuse them).
+#pragma clang fp contract(off)
+
 namespace dddmr {
 
+#ifndef DDDMR_PSPLIT_MAX
+#define DDDMR_PSPLIT_MAX 4   // the path critic's 1-NN search is shared by up to 2^4 lanes per pair
+#endif
 #ifndef DDDMR_SCORE_WPE
 #define DDDMR_SCORE_WPE 2   // min waves per SIMD the register allocator must allow for k_score
 #endif
@@ -131,9 +138,21 @@ __host__ __device__ inline int32_t key_index(int64_t key) {
 // ---------------------------------------------------------------------------
 // float helpers that must not be contracted into fma
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float fmul(float a, float b) { return __fmul_rn(a, b); }
-__device__ __forceinline__ float fadd(float a, float b) { return __fadd_rn(a, b); }
-__device__ __forceinline__ float fsub(float a, float b) { return __fsub_rn(a, b); }
+// (HIP's __fmul_rn / __fadd_rn are plain operators compiled under the translation
+// unit's -ffp-contract=fast, i.e. they still carry the `contract` flag and the
+// backend may fuse them; the pragma below is what actually keeps them apart.)
+__device__ __forceinline__ float fmul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float fadd(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
+__device__ __forceinline__ float fsub(float a, float b) {
+#pragma clang fp contract(off)
+  return a - b;
+}
 
 // FLANN L2_Simple<float>: result = 0; result += diff*diff per dimension.
 __device__ __forceinline__ float l2_simple(float ax, float ay, float az, float bx, float by, float bz) {
@@ -637,7 +656,7 @@ struct TrajHead {     // per-trajectory header in LDS
   double pp_yaw;      // PurePursuitModel: folded yaw of the pose difference
   double stick_sum;   // StickPathModel: sum of the per-step 1-NN distances
   int li;             // local trajectory index (row of the k_rollout state arrays)
-  int pad2;
+  int walked;         // collision work items walked for this trajectory (load feedback)
 };
 
 // OBB record: [0..2] centre, [3..11] axes, [12..14] half extents, [15] cx0|cx1, [16] cy0|cy1,
@@ -752,6 +771,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   unsigned long long* wsum64 = reinterpret_cast<unsigned long long*>(lds_raw + ofs);
 
   __shared__ int alive_pairs_s;
+  __shared__ uint32_t t_item0[kMaxTile + 1];   // first collision item of each trajectory of the tile
+  __shared__ uint32_t t_ubase[kMaxTile + 1];   // ... and of the undecided ones, packed, per walk round
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   // Tile b scores the trajectories in slots b, b + n_tiles, b + 2 n_tiles, ... of the
@@ -781,6 +802,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     h.hit_box = 0; h.hit_mm = 0; h.pad = 0;
     h.pp_dist = 0.0; h.pp_yaw = 0.0; h.stick_sum = 0.0;
     h.li = li;
+    h.walked = 0;
     head[tid] = h;
   }
   // the costmap's row-run index is staged meanwhile (independent loads)
@@ -830,23 +852,6 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     pose_translation(k, bxy, T);
     const float px = (float)T[0], py = (float)T[1], pz = (float)T[2];   // trajectory.cpp:69-75
 
-    // ---- pure pursuit on the last pose (pure_pursuit_model.cpp:86-113) ----
-    if (s == head[j].steps - 1) {
-      // D = inverse(T_traj) * T_plan ; rotation part L^T * planR, translation L^T (planT - T)
-      const double d0 = k.planT[0] - T[0], d1 = k.planT[1] - T[1], d2 = k.planT[2] - T[2];
-      const double tx = L[0] * d0 + L[3] * d1 + L[6] * d2;
-      const double ty = L[1] * d0 + L[4] * d1 + L[7] * d2;
-      const double tz = L[2] * d0 + L[5] * d1 + L[8] * d2;
-      const double D00 = L[0] * k.planR[0] + L[3] * k.planR[3] + L[6] * k.planR[6];
-      const double D10 = L[1] * k.planR[0] + L[4] * k.planR[3] + L[7] * k.planR[6];
-      const double D20 = L[2] * k.planR[0] + L[5] * k.planR[3] + L[8] * k.planR[6];
-      double yaw = 0.0;
-      if (fabs(D20) < 1.0) yaw = atan2(D10, D00);   // getEulerYPR, solution 1
-      // weights are applied in phase E (they are per-critic)
-      head[j].pp_dist = sqrt(tx * tx + ty * ty + tz * tz);
-      head[j].pp_yaw = fmod(yaw + 3.1416, 3.1416);
-    }
-
     // ---- cuboid -> OBB record (collision_model.cpp:85-115) ----
     if (do_coll) {
       // pcl::transformPointCloud(cuboid, Affine3d): double multiply-add, cast to float.
@@ -864,8 +869,10 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         mny = fminf(mny, wy); mxy = fmaxf(mxy, wy);
         mnz = fminf(mnz, wz); mxz = fmaxf(mxz, wz);
         ccx = fadd(ccx, wx); ccy = fadd(ccy, wy); ccz = fadd(ccz, wz);   // centre sum in vertex order
-        const float ux = wx - px, uy = wy - py, uz = wz - pz;
-        vmax2 = fmaxf(vmax2, ux * ux + uy * uy + uz * uz);
+        if (k.rec_pose) {
+          const float ux = wx - px, uy = wy - py, uz = wz - pz;
+          vmax2 = fmaxf(vmax2, ux * ux + uy * uy + uz * uz);
+        }
       };
 #pragma unroll
       for (int vtx = 0; vtx < 4; ++vtx) world_vertex(vtx, v[vtx][0], v[vtx][1], v[vtx][2]);
@@ -907,6 +914,37 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       }
       if (cy1 - cy0 + 1 > k.rows_cap) atomicOr(overflow, 2u);   // host sizes the cells so this cannot happen
     }
+  }
+  // ---- pure pursuit on the last pose (pure_pursuit_model.cpp:86-113): one lane per
+  // trajectory, after the pair loop so that only one wave pays for the atan2 ----
+  if (tid < nt && head[tid].steps > 0) {
+    const int j = tid;
+    const size_t so = (size_t)head[j].li * k.max_steps + (head[j].steps - 1);
+    const double2 cs = st_sc[so];
+    const float2 bxy = st_xy[so];
+    const double c = cs.x, sn = cs.y;
+    double L[9], T[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double r0 = k.R[3 * i + 0], r1 = k.R[3 * i + 1], r2 = k.R[3 * i + 2];
+      L[3 * i + 0] = r0 * c + r1 * sn;
+      L[3 * i + 1] = r1 * c - r0 * sn;
+      L[3 * i + 2] = r2;
+    }
+    pose_translation(k, bxy, T);
+    // D = inverse(T_traj) * T_plan ; rotation part L^T * planR, translation L^T (planT - T)
+    const double d0 = k.planT[0] - T[0], d1 = k.planT[1] - T[1], d2 = k.planT[2] - T[2];
+    const double tx = L[0] * d0 + L[3] * d1 + L[6] * d2;
+    const double ty = L[1] * d0 + L[4] * d1 + L[7] * d2;
+    const double tz = L[2] * d0 + L[5] * d1 + L[8] * d2;
+    const double D00 = L[0] * k.planR[0] + L[3] * k.planR[3] + L[6] * k.planR[6];
+    const double D10 = L[1] * k.planR[0] + L[4] * k.planR[3] + L[7] * k.planR[6];
+    const double D20 = L[2] * k.planR[0] + L[5] * k.planR[3] + L[8] * k.planR[6];
+    double yaw = 0.0;
+    if (fabs(D20) < 1.0) yaw = atan2(D10, D00);   // getEulerYPR, solution 1
+    // weights are applied in phase E (they are per-critic)
+    head[j].pp_dist = sqrt(tx * tx + ty * ty + tz * tz);
+    head[j].pp_yaw = fmod(yaw + 3.1416, 3.1416);
   }
   __syncthreads();
 
@@ -969,8 +1007,12 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         if (wv < wid) wofs += v;
         tot += v;
       }
+      const unsigned long long ex = carry + wofs + incl - cnt;
+      if (q < total_pairs) {
+        const int jq = reinterpret_cast<const int*>(rec + (size_t)q * rec_words)[17] & 0xFFFF;
+        if (q == head[jq].pair_base) t_item0[jq] = (uint32_t)ex;   // items in front of the trajectory's first pair
+      }
       if (cnt) {
-        const unsigned long long ex = carry + wofs + incl - cnt;
         uint32_t ci = (uint32_t)(ex >> 32), itn = (uint32_t)ex;
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
@@ -988,7 +1030,12 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     }
     const int nseg = (int)(carry >> 32);
     const uint32_t total = (uint32_t)carry;
-    if (tid == 0) pref[nseg] = total;
+    if (tid == 0) {
+      pref[nseg] = total;
+      t_item0[nt] = total;
+      for (int j = nt - 1; j >= 0; --j)               // trajectories without poses own no items
+        if (head[j].steps == 0) t_item0[j] = t_item0[j + 1];
+    }
     __syncthreads();
 
     DDDMR_STAMP(5);   // end of phase D2
@@ -996,63 +1043,99 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
 #ifdef DDDMR_PHASE_STAMPS
     if (tid == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * kStampSlots + 9] = total;
 #endif
-    const uint32_t chunk = (total + kScoreThreads - 1) / kScoreThreads;
-    uint32_t it = (uint32_t)tid * chunk;
-    const uint32_t it1 = min(total, it + chunk);
-    if (it < it1) {
-      int lo = 0, hi = nseg;                        // largest segment with pref[seg] <= it
+    auto walk_item = [&](const uint32_t it, const int sg) {
+      const uint32_t sl_len = seg_len[sg];
+      const int q = (int)(sl_len & 0xFFFu);
+      const float* rq = rec + (size_t)q * rec_words;
+      const int jw = reinterpret_cast<const int*>(rq)[17];
+      const int j = jw & 0xFFFF;
+      const bool use_radius = (jw & 0x10000) == 0;
+      const bool hb = !need_box || head[j].hit_box != 0;
+      const bool hm = !need_mm || head[j].hit_mm != 0;
+      if (hb && hm) return;                       // trajectory already decided
+      atomicAdd(&head[j].walked, 1);              // load feedback: items walked for this trajectory
+      const uint32_t off = (it - pref[sg]) * kItem;
+      const uint32_t p0 = seg_p[sg] + off;
+      const uint32_t n = min((uint32_t)kItem, (sl_len >> 12) - off);
+      // kItem independent loads in flight (the sorted array is padded by kItem)
+      float4 pt[kItem];
+  #pragma unroll
+      for (int u = 0; u < kItem; ++u) pt[u] = sorted[p0 + u];
+      float r[18];
+  #pragma unroll
+      for (int u = 0; u < 15; ++u) r[u] = rq[u];
+      r[15] = r[16] = r[17] = 0.f;             // pose, only read when the radius test is live
+      if (use_radius || need_mm) { r[15] = rq[18]; r[16] = rq[19]; r[17] = rq[20]; }
+      bool fb = false, fm = false;
+      if (need_box) {
+        int hits = 0;
+  #pragma unroll
+        for (int u = 0; u < kItem; u += 2) {
+          const int h2 = box_test2(r, pt[u], pt[u + 1], use_radius);
+          hits |= ((uint32_t)u < n ? (h2 & 1) : 0) | ((uint32_t)(u + 1) < n ? (h2 & 2) : 0);
+        }
+        fb = hits != 0;
+      }
+      if (need_mm) {
+  #pragma unroll
+        for (int u = 0; u < kItem; ++u) {
+          // radiusSearch(pose, 1.0): FLANN keeps dist^2 < r^2
+          const bool in = (uint32_t)u < n && l2_simple(r[15], r[16], r[17], pt[u].x, pt[u].y, pt[u].z) < 1.0f;
+          const float* rm = rq + mm_ofs;
+          fm |= in && (pt[u].x >= rm[0] && pt[u].x <= rm[3] && pt[u].y >= rm[1] && pt[u].y <= rm[4] &&
+                       pt[u].z >= rm[2] && pt[u].z <= rm[5]);
+        }
+      }
+      if (fb) atomicOr(&head[j].hit_box, 1);
+      if (fm) atomicOr(&head[j].hit_mm, 1);
+    };
+    // Two rounds.  Round 0 probes: every lane walks ONE item, the lanes evenly spread
+    // over the list, which settles most colliding trajectories at once (~60 probes
+    // each).  Round 1 deals the items of the still undecided trajectories evenly to
+    // the lanes, so that nobody idles behind lanes whose share was skipped.
+    auto find_seg = [&](uint32_t item, int lo) {      // largest segment >= lo with pref[seg] <= item
+      int hi = nseg;
       while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
-        if (pref[mid] <= it) lo = mid; else hi = mid;
+        if (pref[mid] <= item) lo = mid; else hi = mid;
       }
-      int sg = lo;
-      for (; it < it1; ++it) {
-        while (pref[sg + 1] <= it) ++sg;
-        const uint32_t sl_len = seg_len[sg];
-        const int q = (int)(sl_len & 0xFFFu);
-        const float* rq = rec + (size_t)q * rec_words;
-        const int jw = reinterpret_cast<const int*>(rq)[17];
-        const int j = jw & 0xFFFF;
-        const bool use_radius = (jw & 0x10000) == 0;
-        const bool hb = !need_box || head[j].hit_box != 0;
-        const bool hm = !need_mm || head[j].hit_mm != 0;
-        if (hb && hm) continue;                     // trajectory already decided
-        atomicAdd(&head[j].pad, 1);                 // load feedback: items walked for this trajectory
-        const uint32_t off = (it - pref[sg]) * kItem;
-        const uint32_t p0 = seg_p[sg] + off;
-        const uint32_t n = min((uint32_t)kItem, (sl_len >> 12) - off);
-        // kItem independent loads in flight (the sorted array is padded by kItem)
-        float4 pt[kItem];
-#pragma unroll
-        for (int u = 0; u < kItem; ++u) pt[u] = sorted[p0 + u];
-        float r[18];
-#pragma unroll
-        for (int u = 0; u < 15; ++u) r[u] = rq[u];
-        r[15] = r[16] = r[17] = 0.f;             // pose, only read when the radius test is live
-        if (use_radius || need_mm) { r[15] = rq[18]; r[16] = rq[19]; r[17] = rq[20]; }
-        bool fb = false, fm = false;
-        if (need_box) {
-          int hits = 0;
-#pragma unroll
-          for (int u = 0; u < kItem; u += 2) {
-            const int h2 = box_test2(r, pt[u], pt[u + 1], use_radius);
-            hits |= ((uint32_t)u < n ? (h2 & 1) : 0) | ((uint32_t)(u + 1) < n ? (h2 & 2) : 0);
-          }
-          fb = hits != 0;
+      return lo;
+    };
+    const int n_rounds = total > (uint32_t)kScoreThreads ? 2 : 1;
+    for (int round = 0; round < n_rounds; ++round) {
+      if (tid == 0) {
+        uint32_t acc = 0;
+        for (int j = 0; j < nt; ++j) {
+          t_ubase[j] = acc;
+          const bool decided = round > 0 && (!need_box || head[j].hit_box != 0) && (!need_mm || head[j].hit_mm != 0);
+          if (!decided) acc += t_item0[j + 1] - t_item0[j];
         }
-        if (need_mm) {
-#pragma unroll
-          for (int u = 0; u < kItem; ++u) {
-            // radiusSearch(pose, 1.0): FLANN keeps dist^2 < r^2
-            const bool in = (uint32_t)u < n && l2_simple(r[15], r[16], r[17], pt[u].x, pt[u].y, pt[u].z) < 1.0f;
-            const float* rm = rq + mm_ofs;
-            fm |= in && (pt[u].x >= rm[0] && pt[u].x <= rm[3] && pt[u].y >= rm[1] && pt[u].y <= rm[4] &&
-                         pt[u].z >= rm[2] && pt[u].z <= rm[5]);
+        t_ubase[nt] = acc;
+      }
+      __syncthreads();
+      const uint32_t tot_r = t_ubase[nt];
+      const uint32_t chunk = (tot_r + kScoreThreads - 1) / kScoreThreads;
+      uint32_t p = (uint32_t)tid * chunk;
+      const uint32_t p1 = min(tot_r, p + ((round == 0 && n_rounds == 2) ? 1u : chunk));
+      if (p < p1) {
+        int j = 0;
+        while (t_ubase[j + 1] <= p) ++j;
+        uint32_t it = t_item0[j] + (p - t_ubase[j]);
+        int sg = find_seg(it, 0);
+        for (;;) {
+          walk_item(it, sg);
+          if (++p >= p1) break;
+          if (p >= t_ubase[j + 1]) {                  // next undecided trajectory
+            do { ++j; } while (t_ubase[j + 1] <= p);
+            it = t_item0[j] + (p - t_ubase[j]);
+            sg = find_seg(it, sg);
+          } else {
+            ++it;
+            while (pref[sg + 1] <= it) ++sg;
           }
         }
-        if (fb) atomicOr(&head[j].hit_box, 1);
-        if (fm) atomicOr(&head[j].hit_mm, 1);
       }
+      __syncthreads();
     }
   }
   __syncthreads();
@@ -1075,33 +1158,50 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     alive_pairs_s = acc;
   }
   __syncthreads();
-  for (int q2 = tid; q2 < alive_pairs_s; q2 += kScoreThreads) {
-    int j = 0;
-    while (j + 1 < nt && head[j + 1].pad <= q2) ++j;      // (dead trajectories have empty ranges)
-    const int s = q2 - head[j].pad;
-    const float2 bxy = st_xy[(size_t)head[j].li * k.max_steps + s];
-    double T[3];
-    pose_translation(k, bxy, T);
-    const float px = (float)T[0], py = (float)T[1], pz = (float)T[2];
-    // exact 1-NN distance to the prune plan (FLANN float distance)
-    {
+  {
+    // G lanes share one pair, each scanning a slice of the plan; the minimum is exact
+    // whatever the split, so the result does not depend on G.
+    const int alive = alive_pairs_s;
+    int lg = 0;
+    while (lg < DDDMR_PSPLIT_MAX && (alive << (lg + 1)) <= kScoreThreads) ++lg;
+    const int G = 1 << lg;
+    const int per = (k.m + G - 1) >> lg;
+    for (int base = 0; base < (alive << lg); base += kScoreThreads) {
+      const int idx = base + tid;
+      const int q2 = idx >> lg, g = idx & (G - 1);
+      const bool valid = q2 < alive;
+      int j = 0, s = 0;
+      float px = 0.f, py = 0.f, pz = 0.f;
+      if (valid) {
+        while (j + 1 < nt && head[j + 1].pad <= q2) ++j;    // (dead trajectories have empty ranges)
+        s = q2 - head[j].pad;
+        const float2 bxy = st_xy[(size_t)head[j].li * k.max_steps + s];
+        double T[3];
+        pose_translation(k, bxy, T);
+        px = (float)T[0]; py = (float)T[1]; pz = (float)T[2];
+      }
+      // exact 1-NN distance to the prune plan (FLANN float distance)
       float best = 3.402823466e+38f;
-      int i = 0;
-      for (; i + 4 <= k.m; i += 4) {
-        const float4 p0 = plan[i], p1 = plan[i + 1], p2 = plan[i + 2], p3 = plan[i + 3];
-        const f2 da = l2_simple2(f2{p0.x, p1.x}, f2{p0.y, p1.y}, f2{p0.z, p1.z}, px, py, pz);
-        const f2 db = l2_simple2(f2{p2.x, p3.x}, f2{p2.y, p3.y}, f2{p2.z, p3.z}, px, py, pz);
-        best = fminf(fminf(best, fminf(da.x, da.y)), fminf(db.x, db.y));
+      if (valid) {
+        int i = g * per;
+        const int i1 = min(k.m, i + per);
+        for (; i + 4 <= i1; i += 4) {
+          const float4 p0 = plan[i], p1 = plan[i + 1], p2 = plan[i + 2], p3 = plan[i + 3];
+          const f2 da = l2_simple2(f2{p0.x, p1.x}, f2{p0.y, p1.y}, f2{p0.z, p1.z}, px, py, pz);
+          const f2 db = l2_simple2(f2{p2.x, p3.x}, f2{p2.y, p3.y}, f2{p2.z, p3.z}, px, py, pz);
+          best = fminf(fminf(best, fminf(da.x, da.y)), fminf(db.x, db.y));
+        }
+        for (; i < i1; ++i) {
+          const float4 pp = plan[i];
+          best = fminf(best, l2_simple(pp.x, pp.y, pp.z, px, py, pz));
+        }
       }
-      for (; i < k.m; ++i) {
-        const float4 pp = plan[i];
-        best = fminf(best, l2_simple(pp.x, pp.y, pp.z, px, py, pz));
-      }
-      dist[(size_t)j * S1 + s] = sqrtf(best);
+      for (int o = 1; o < G; o <<= 1) best = fminf(best, __shfl_xor(best, o, 64));
+      if (valid && g == 0) dist[(size_t)j * S1 + s] = sqrtf(best);
     }
-
   }
   __syncthreads();
+  DDDMR_STAMP(8);   // end of phase P
 
   // StickPath's sum of per-step distances (stick_path_model.cpp:62-73): one wave per
   // trajectory, lanes stride the steps, fixed xor-shuffle tree in double (the
@@ -1181,7 +1281,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     // what this trajectory cost (in collision work items): the walk, the path critics'
     // 1-NN searches when it got that far, and the per-pair phases
     const bool collided = (need_box && h.hit_box) || (need_mm && h.hit_mm);
-    traj_load[li] = (uint32_t)h.pad + (uint32_t)h.steps * (2u + (collided ? 0u : (uint32_t)((k.m + 15) >> 4)));
+    traj_load[li] = (uint32_t)h.walked + (uint32_t)h.steps * (2u + (collided ? 0u : (uint32_t)((k.m + 15) >> 4)));
   }
   // wave-0 shuffle min-reduction of the packed keys, one atomic per workgroup
   if (tid < 64) {

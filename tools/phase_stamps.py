@@ -34,6 +34,8 @@ with LocalPlanner([sc.theory], max_points=max(len(sc.cloud), 16)) as lp:
     for i, nm in enumerate(names):
         d = (st[:, i + 1] - st[:, i]) / 1000.0   # kilo-cycles (s_memtime counts shader clocks)
         print(f"  {nm:18s} mean {d.mean():8.2f} kc  p50 {np.percentile(d,50):8.2f}  p99 {np.percentile(d,99):8.2f}  max {d.max():8.2f}")
+    dP = (st[:, 8] - st[:, 6]) / 1000.0; dE = (st[:, 7] - st[:, 8]) / 1000.0
+    print(f"    of which P path 1-NN mean {dP.mean():8.2f} kc max {dP.max():8.2f};  E stick+score+argmin mean {dE.mean():8.2f} max {dE.max():8.2f}")
     life = (st[:, 7] - st[:, 0]) / 1000.0
     print(f"  workgroup lifetime mean {life.mean():.2f} us max {life.max():.2f} us; first start -> last end {(st[:,7].max()-t0)/1000.0:.2f} us")
     start = (st[:, 0] - t0) / 1000.0
