@@ -165,7 +165,7 @@ struct dddmr_rollout_ctx {
   float4* cloud_dev[2] = {nullptr, nullptr};
   uint32_t cloud_n[2] = {0, 0};
   uint2* pt_slot = nullptr;
-  float4* sorted = nullptr;
+  Pt3* sorted = nullptr;
   uint32_t *cell_count = nullptr, *cell_start = nullptr;
   float* axes_dev = nullptr;
   float4* samples_dev = nullptr;
@@ -421,8 +421,8 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
       HIPCHK(ctx, hipEventCreateWithFlags(&ctx->cloud_ready[i], hipEventDisableTiming));
     }
     HIPCHK(ctx, hipMalloc(&ctx->pt_slot, P * sizeof(uint2)));
-    HIPCHK(ctx, hipMalloc(&ctx->sorted, (P + kItem) * sizeof(float4)));
-    HIPCHK(ctx, hipMemset(ctx->sorted, 0, (P + kItem) * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&ctx->sorted, (P + kItem) * sizeof(Pt3)));
+    HIPCHK(ctx, hipMemset(ctx->sorted, 0, (P + kItem) * sizeof(Pt3)));
     HIPCHK(ctx, hipMalloc(&ctx->cell_count, (kCapCells + 1) * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->cell_start, (kCapCells + 1) * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(ctx->cell_count, 0, (kCapCells + 1) * sizeof(uint32_t)));

@@ -45,6 +45,9 @@ constexpr int kMaxTile = 16;          // trajectories per workgroup (upper bound
 constexpr int kMaxPlan = 512;         // prune-plan poses kept in LDS
 constexpr int kInlineAxes = 192;      // sample-axis floats that travel inside the kernel arguments
 constexpr int64_t kKeyNone = INT64_MAX;
+// a cell-sorted point: 12 bytes -- the collision walk is bound by the bytes the lanes
+// pull through the vector L1, and the intensity word is never read
+struct Pt3 { float x, y, z; };
 constexpr int kKeyIndexBits = 24;     // 16.7 M samples per tick
 
 // Per-tick constants, passed by value (kernarg segment => scalar loads).
@@ -168,6 +171,60 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
   return fadd(fadd(fmul(ax, bx), fmul(ay, by)), fmul(az, bz));
 }
 
+// sin and cos of a heading in double.  The rollout's phase B is bound by exactly this
+// (one call per pose), and ocml's sincos spends most of its instructions on argument
+// ranges a heading never has.  fdlibm's algorithm for |x| < 2^20 pi/2: Cody-Waite
+// reduction with pi/2 in 33-bit pieces (118 bits, exact products), then the
+// __kernel_sin / __kernel_cos polynomials on [-pi/4, pi/4] with the reduction's tail;
+// < 0.8 ulp (ocml and glibc: <= 1 ulp), ~50 double operations.  Larger arguments fall
+// back to ocml.
+__device__ __forceinline__ void sincos_heading(const double x, double* sn, double* cs) {
+  if (fabs(x) > 1.0e5) {
+    sincos(x, sn, cs);
+    return;
+  }
+  const double fn = rint(x * 6.36619772367581382433e-01);
+  const int n = (int)fn;
+  double r = x - fn * 1.57079632673412561417e+00;
+  const double t = r;
+  double w = fn * 6.07710050630396597660e-11;
+  r = t - w;
+  w = fn * 2.02226624879595063154e-21 - ((t - r) - w);
+  const double y0 = r - w;
+  const double y1 = (r - y0) - w;
+  const double z = y0 * y0;
+  const double v = z * y0;
+  const double ps = 8.33333333332248946124e-03 +
+                    z * (-1.98412698298579493134e-04 +
+                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double s = y0 - ((z * (0.5 * y1 - v * ps) - y1) - v * -1.66666666666666324348e-01);
+  const double pc = z * (4.16666666666666019037e-02 +
+                         z * (-1.38888888888741095749e-03 +
+                              z * (2.48015872894767294178e-05 +
+                                   z * (-2.75573143513906633035e-07 +
+                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double hz = 0.5 * z;
+  const double w2 = 1.0 - hz;
+  const double c = w2 + (((1.0 - w2) - hz) + (z * pc - y0 * y1));
+  const int q = n & 3;
+  *sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+  *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+}
+
+// cos/sin(M_PI_2 + theta) in double from sin/cos(theta) (omni_simple...cpp:501-502).  The
+// argument the reference hands to libm is t = fl(fl(pi/2) + theta) = pi/2 + theta - e
+// with e = (pi/2 - fl(pi/2)) + (rounding error of the sum, exact by Fast2Sum), so
+// cos t = -sin(theta - e), sin t = cos(theta - e): first-order corrections of the values
+// already at hand (|e| < 3e-16, the neglected term < 1e-31) instead of a second sincos.
+__device__ __forceinline__ void sincos_quarter_ahead(const double ang, const double sn, const double cs, double* s2,
+                                                     double* c2) {
+  const double t = M_PI_2 + ang;
+  const double err = fabs(ang) <= M_PI_2 ? (M_PI_2 - t) + ang : (ang - t) + M_PI_2;   // (pi/2_fl + theta) - t
+  const double e = 6.123233995736766e-17 + err;
+  *c2 = -sn + e * cs;
+  *s2 = cs + e * sn;
+}
+
 // ---------------------------------------------------------------------------
 // binning: cloud -> cell-sorted local costmap tile
 // ---------------------------------------------------------------------------
@@ -245,11 +302,14 @@ __global__ __launch_bounds__(256) void k_bin_reset(DevTick k, uint32_t* __restri
 __global__ __launch_bounds__(256) void k_bin_scatter(DevTick k, const float4* __restrict__ cloud,
                                                      const uint2* __restrict__ pt_slot,
                                                      const uint32_t* __restrict__ cell_start,
-                                                     float4* __restrict__ sorted) {
+                                                     Pt3* __restrict__ sorted) {
   const int stride = gridDim.x * blockDim.x;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k.n_points; i += stride) {
     const uint2 slot = pt_slot[i];
-    if (slot.x != 0xFFFFFFFFu) sorted[cell_start[slot.x] + slot.y] = cloud[i];
+    if (slot.x != 0xFFFFFFFFu) {
+      const float4 p = cloud[i];
+      sorted[cell_start[slot.x] + slot.y] = Pt3{p.x, p.y, p.z};
+    }
   }
 }
 
@@ -404,7 +464,7 @@ __device__ __forceinline__ void rollout_block(const DevTick& k, const int block,
     if (s <= ns) {
       const double ang = (double)th[idx];
       double sn, cs;
-      sincos(ang, &sn, &cs);
+      sincos_heading(ang, &sn, &cs);
       // heading after step s-1 = theta_s: the pose's rotation (dd_simple...cpp:416)
       if (s >= 1) st_sc[(size_t)(l0 + j) * k.max_steps + (s - 1)] = make_double2(cs, sn);
       if (s < ns) {
@@ -412,17 +472,8 @@ __device__ __forceinline__ void rollout_block(const DevTick& k, const int block,
         const float cf = (float)cs, sf = (float)sn;      // cos/sin(float) overloads
         double ix = (double)fmul(vx, cf), iy = (double)fmul(vx, sf);
         if (omni) {
-          // cos/sin(M_PI_2 + theta) in double (omni_simple...cpp:501-502).  The argument
-          // the reference hands to libm is t = fl(fl(pi/2) + theta) = pi/2 + theta - e with
-          // e = (pi/2 - fl(pi/2)) + (rounding error of the sum, exact by Fast2Sum), so
-          // cos t = -sin(theta - e), sin t = cos(theta - e): first-order corrections of
-          // the values already at hand (|e| < 3e-16, the neglected term < 1e-31) instead
-          // of a second sincos -- the double sincos is what bounds this phase.
-          const double t = M_PI_2 + ang;
-          const double err = fabs(ang) <= M_PI_2 ? (M_PI_2 - t) + ang : (ang - t) + M_PI_2;   // (pi/2_fl + theta) - t
-          const double e = 6.123233995736766e-17 + err;
-          const double c2 = -sn + e * cs;
-          const double s2 = cs + e * sn;
+          double s2, c2;
+          sincos_quarter_ahead(ang, sn, cs, &s2, &c2);   // cos/sin(M_PI_2 + theta), omni_simple...cpp:501-502
           ix += (double)vy * c2;
           iy += (double)vy * s2;
         }
@@ -710,7 +761,7 @@ __device__ __forceinline__ f2 dot3_2(f2 dx, f2 dy, f2 dz, float a, float b, floa
 }
 // box (and radius) verdicts of two cloud points against one OBB record:
 // bit 0 / bit 1 = point a / b collides (collision_model.cpp:122-139)
-__device__ __forceinline__ int box_test2(const float* r, const float4 a, const float4 b, bool use_radius) {
+__device__ __forceinline__ int box_test2(const float* r, const Pt3 a, const Pt3 b, bool use_radius) {
 #pragma clang fp contract(off)
   const f2 x = {a.x, b.x}, y = {a.y, b.y}, z = {a.z, b.z};
   const f2 dx = x - r[0], dy = y - r[1], dz = z - r[2];
@@ -738,7 +789,7 @@ template <int kScoreThreads>
 __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     DevTick k, const TrajInfo* __restrict__ info, const double2* __restrict__ st_sc, const float2* __restrict__ st_xy,
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
-    const float4* __restrict__ sorted, double* __restrict__ costs, int32_t* __restrict__ steps_out,
+    const Pt3* __restrict__ sorted, double* __restrict__ costs, int32_t* __restrict__ steps_out,
     float4* __restrict__ samples_out, int64_t* __restrict__ best_key, uint32_t* __restrict__ overflow,
     uint32_t* __restrict__ ticket, DevResult* __restrict__ result, const uint32_t* __restrict__ assign,
     uint32_t* __restrict__ traj_load) {
@@ -1058,7 +1109,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       const uint32_t p0 = seg_p[sg] + off;
       const uint32_t n = min((uint32_t)kItem, (sl_len >> 12) - off);
       // kItem independent loads in flight (the sorted array is padded by kItem)
-      float4 pt[kItem];
+      Pt3 pt[kItem];
   #pragma unroll
       for (int u = 0; u < kItem; ++u) pt[u] = sorted[p0 + u];
       float r[18];
@@ -1364,18 +1415,18 @@ __global__ void k_trajectory_poses(DevTick k, int li, const float4* __restrict__
   float px = 0.f, py = 0.f, pth = 0.f;
   for (int s = 0; s < ns; ++s) {
     double sn, cs;
-    sincos((double)pth, &sn, &cs);
+    sincos_heading((double)pth, &sn, &cs);
     double ix = (double)fmul(smp.x, (float)cs), iy = (double)fmul(smp.x, (float)sn);
     if (k.kind == DDDMR_THEORY_OMNI_SIMPLE) {
       double s2, c2;
-      sincos(M_PI_2 + (double)pth, &s2, &c2);
+      sincos_quarter_ahead((double)pth, sn, cs, &s2, &c2);
       ix += (double)smp.y * c2;
       iy += (double)smp.y * s2;
     }
     px = (float)((double)px + ix * dt);
     py = (float)((double)py + iy * dt);
     pth = (float)((double)pth + (double)smp.z * dt);
-    sincos((double)pth, &sn, &cs);
+    sincos_heading((double)pth, &sn, &cs);
     double L[9], T[3];
     for (int i = 0; i < 3; ++i) {
       const double r0 = k.R[3 * i + 0], r1 = k.R[3 * i + 1], r2 = k.R[3 * i + 2];

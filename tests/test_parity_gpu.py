@@ -356,6 +356,30 @@ def test_c4_batch_65536_sharded_over_8_contexts():
     assert sharding.key_index(min(keys)) == res0.best_index
 
 
+def test_load_feedback_is_result_neutral():
+    """The tiles of later ticks are dealt by the load the previous tick measured
+    (assignment workgroups, 16 groups at 65536 trajectories).  Whatever the deal --
+    strided first tick, fed-back later ticks, a theory switch in between -- costs,
+    steps and the winner stay identical."""
+    sc = scenes.bench_scene("C4")
+    name = sc.theory.name.decode()
+    rot = configs.rotate_inplace_shipped("rot")
+    with LocalPlanner([sc.theory, rot], max_points=len(sc.cloud), max_trajectories=1 << 17) as lp:
+        lp.set_cloud(sc.cloud)
+        lp.setPlan(sc.plan)
+        r0 = lp.tick(name, sc.tick)
+        c0, s0, _ = (a.copy() for a in lp.debug())
+        for t in range(4):
+            if t == 2:      # another theory in between resets the feedback
+                lp.tick("rot", scenes.tick_input())
+            r = lp.tick(name, sc.tick)
+            c, s_, _ = lp.debug()
+            np.testing.assert_array_equal(c, c0)
+            np.testing.assert_array_equal(s_, s0)
+            assert (r.key, r.best_index, r.best_cost) == (r0.key, r0.best_index, r0.best_cost)
+    assert r0.n_samples == 65536
+
+
 def test_moving_robot_sequence_keeps_parity():
     """State carried between ticks (launch-order feedback, double-buffered cloud,
     sampled timing) must never leak into results: a robot driving down the C2
