@@ -24,6 +24,8 @@ ERR_HIP = -3
 ERR_UNKNOWN_THEORY = -4
 ERR_CAPACITY = -5
 ERR_STATE = -6
+OPINION_PASS = 0                 # perception_3d::PerceptionOpinion
+OPINION_PATH_BLOCKED_WAIT = 1
 
 # dddmr_planner_state (dddmr_sys_core/include/dddmr_sys_core/dddmr_enum_states.h:46-54)
 TF_FAIL = 0
@@ -157,6 +159,7 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_resolve",
     "dddmr_rollout_get_debug",
     "dddmr_rollout_get_best_poses",
+    "dddmr_rollout_path_blocked",
     "dddmr_rollout_pack_key",
     "dddmr_rollout_key_index",
     "dddmr_rollout_last_error",
@@ -212,6 +215,9 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_get_debug.restype = C.c_int
     lib.dddmr_rollout_get_best_poses.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.dddmr_rollout_get_best_poses.restype = C.c_int
+    lib.dddmr_rollout_path_blocked.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.c_double, C.POINTER(C.c_double),
+                                               C.POINTER(C.c_int32), C.c_void_p]
+    lib.dddmr_rollout_path_blocked.restype = C.c_int
     lib.dddmr_rollout_pack_key.argtypes = [C.c_double, C.c_uint32]
     lib.dddmr_rollout_pack_key.restype = C.c_int64
     lib.dddmr_rollout_key_index.argtypes = [C.c_int64]

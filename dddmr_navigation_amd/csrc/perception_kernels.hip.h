@@ -219,4 +219,51 @@ inline int perception_feed(PerceptionScratch& s, FeedParams f, const float* scan
   return 0;
 }
 
+// ---------------------------------------------------------------------------
+// PathBlockedStrategy::selfMark
+// (dddmr_perception_3d/plugins/path_blocked_strategy.cpp:56-100): which forward points of
+// the prune-plan cloud have an observation point within check_radius.  The reference
+// builds a second kd-tree on the aggregate observation for M radius searches (:68-83);
+// here every cloud point is tested against the forward plan points kept in LDS (a
+// bounding box of the plan, grown by the radius, rejects nearly all of them first).
+// FLANN's L2_Simple float distance, strict `<` against static_cast<float>(r * r).
+// ---------------------------------------------------------------------------
+constexpr int kBlockedMaxPlan = 1024;   // pcl_prune_plan_ points (the nearest pose appears twice)
+struct BlockedParams {
+  int n_points;
+  int m;            // plan points
+  float r2;
+  float lo[3], hi[3];
+};
+
+__global__ __launch_bounds__(256) void k_path_blocked(BlockedParams b, const float4* __restrict__ cloud,
+                                                      const float4* __restrict__ plan_xyzi,
+                                                      uint32_t* __restrict__ flags /* [(m + 31) / 32] */) {
+  __shared__ float4 plan[kBlockedMaxPlan];
+  __shared__ uint32_t hit[kBlockedMaxPlan / 32];
+  for (int i = threadIdx.x; i < b.m; i += blockDim.x) plan[i] = plan_xyzi[i];
+  for (int i = threadIdx.x; i < kBlockedMaxPlan / 32; i += blockDim.x) hit[i] = 0u;
+  __syncthreads();
+  const int stride = gridDim.x * blockDim.x;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < b.n_points; i += stride) {
+    const float4 p = cloud[i];
+    if (!(p.x >= b.lo[0] && p.x <= b.hi[0] && p.y >= b.lo[1] && p.y <= b.hi[1] && p.z >= b.lo[2] && p.z <= b.hi[2]))
+      continue;
+    for (int j = 0; j < b.m; ++j) {
+      const float4 q = plan[j];
+      if (q.w < 0.f) continue;                    // backward of the robot (:80-81)
+      float d = q.x - p.x;
+      float r = d * d;
+      d = q.y - p.y;
+      r = r + d * d;
+      d = q.z - p.z;
+      r = r + d * d;
+      if (r < b.r2) atomicOr(&hit[j >> 5], 1u << (j & 31));
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (b.m + 31) / 32; i += blockDim.x)
+    if (hit[i]) atomicOr(&flags[i], hit[i]);
+}
+
 }  // namespace dddmr

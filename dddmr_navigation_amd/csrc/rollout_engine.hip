@@ -178,6 +178,8 @@ struct dddmr_rollout_ctx {
   DevResult* result_dev = nullptr;   // device alias of result_host (host-mapped)
   uint32_t* tickets = nullptr;       // [0] binning ticket, [1] scoring ticket
   // load feedback (device): per-trajectory load of the last tick, tile assignment of this one
+  float4* blocked_plan = nullptr;      // PathBlockedStrategy scratch (lazily allocated)
+  uint32_t* blocked_flags = nullptr;
   uint32_t* traj_load = nullptr;
   uint32_t* assign = nullptr;
   int load_theory = -1, load_nlocal = -1;   // what traj_load describes
@@ -232,6 +234,8 @@ struct dddmr_rollout_ctx {
 };
 
 namespace {
+
+void release_cloud(dddmr_rollout_ctx* c);
 
 int fail(dddmr_rollout_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
@@ -348,7 +352,7 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   }
   void* dev[] = {ctx->pt_slot, ctx->sorted, ctx->cell_count, ctx->cell_start, ctx->axes_dev,
                  ctx->samples_dev, ctx->plan_dev, ctx->costs, ctx->steps, ctx->samples_out,
-                 ctx->best_key, ctx->overflow, ctx->tickets, ctx->poses_dev, ctx->traj_load, ctx->assign};
+                 ctx->best_key, ctx->overflow, ctx->tickets, ctx->poses_dev, ctx->traj_load, ctx->assign, ctx->blocked_plan, ctx->blocked_flags};
   for (void* p : dev)
     if (p) (void)hipFree(p);
   perception_free(ctx->feed);
@@ -556,6 +560,77 @@ int dddmr_rollout_get_cloud(dddmr_rollout_ctx* ctx, float* xyzi_out, size_t capa
   if (!xyzi_out) return DDDMR_OK;
   if (capacity < n) return fail(ctx, DDDMR_ERR_CAPACITY, "get_cloud: capacity %zu < %u", capacity, n);
   if (n) HIPCHK(ctx, hipMemcpy(xyzi_out, ctx->cloud_dev[idx], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_path_blocked(dddmr_rollout_ctx* ctx, const float* plan_xyzi, size_t n_plan, double check_radius,
+                               double* ratio, int32_t* opinion, uint8_t* blocked_flags) {
+  if (!ctx || !ratio || !opinion) return DDDMR_ERR_BAD_ARG;
+  if (n_plan > 0 && !plan_xyzi) return fail(ctx, DDDMR_ERR_BAD_ARG, "path_blocked: null plan");
+  if (n_plan > (size_t)kBlockedMaxPlan)
+    return fail(ctx, DDDMR_ERR_CAPACITY, "path_blocked: %zu plan points > %d", n_plan, kBlockedMaxPlan);
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "path_blocked while a tick_begin is pending");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  *ratio = 0.0;
+  *opinion = DDDMR_OPINION_PASS;
+  if (blocked_flags) std::memset(blocked_flags, 0, n_plan);
+  // pin the front cloud like a tick does
+  int cidx;
+  bool pending;
+  {
+    std::lock_guard<std::mutex> lk(ctx->cloud_mu);
+    cidx = ctx->front;
+    ctx->busy = cidx;
+    pending = ctx->front_pending;       // stays set: the next tick still has to wait for the upload
+  }
+  struct Release { dddmr_rollout_ctx* c; ~Release() { release_cloud(c); } } release{ctx};
+  const uint32_t n_points = ctx->cloud_n[cidx];
+  if (n_points <= 5 || n_plan == 0) return DDDMR_OK;                  // path_blocked_strategy.cpp:62-64
+  BlockedParams b;
+  b.n_points = (int)n_points;
+  b.m = (int)n_plan;
+  b.r2 = static_cast<float>(check_radius * check_radius);             // pcl::KdTreeFLANN::radiusSearch
+  bool any = false;
+  for (int a = 0; a < 3; ++a) { b.lo[a] = 3.402823466e+38f; b.hi[a] = -3.402823466e+38f; }
+  for (size_t i = 0; i < n_plan; ++i) {
+    if (plan_xyzi[4 * i + 3] < 0) continue;
+    any = true;
+    for (int a = 0; a < 3; ++a) {
+      b.lo[a] = std::min(b.lo[a], plan_xyzi[4 * i + a]);
+      b.hi[a] = std::max(b.hi[a], plan_xyzi[4 * i + a]);
+    }
+  }
+  if (any) {
+    // conservative reject box: a point farther than r from the plan's box along an axis cannot be within r
+    const float grow = (float)(std::fabs(check_radius) * 1.000001 + 1e-6);
+    for (int a = 0; a < 3; ++a) {
+      b.lo[a] = std::nextafter(b.lo[a] - grow, -3.402823466e+38f);
+      b.hi[a] = std::nextafter(b.hi[a] + grow, 3.402823466e+38f);
+    }
+    if (!ctx->blocked_plan) {
+      HIPCHK(ctx, hipMalloc(&ctx->blocked_plan, kBlockedMaxPlan * sizeof(float4)));
+      HIPCHK(ctx, hipMalloc(&ctx->blocked_flags, (kBlockedMaxPlan / 32) * sizeof(uint32_t)));
+    }
+    if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->blocked_plan, plan_xyzi, n_plan * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->blocked_flags, 0, (kBlockedMaxPlan / 32) * sizeof(uint32_t), ctx->stream));
+    const int blocks = (int)std::min<uint32_t>(1024, (n_points + 255) / 256);
+    hipLaunchKernelGGL(k_path_blocked, dim3(blocks), dim3(256), 0, ctx->stream, b, ctx->cloud_dev[cidx],
+                       ctx->blocked_plan, ctx->blocked_flags);
+    uint32_t words[kBlockedMaxPlan / 32];
+    HIPCHK(ctx, hipMemcpyAsync(words, ctx->blocked_flags, sizeof(words), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    size_t blocked = 0;
+    for (size_t i = 0; i < n_plan; ++i) {
+      const bool hit = (words[i >> 5] >> (i & 31)) & 1u;
+      if (hit) ++blocked;
+      if (blocked_flags) blocked_flags[i] = hit ? 1 : 0;
+    }
+    const float orig = (float)n_plan, blk = (float)blocked;           // float division, double scale (:91-93)
+    *ratio = (blk) / (orig) * 100.0;
+  }
+  if (*ratio > 0.0) *opinion = DDDMR_OPINION_PATH_BLOCKED_WAIT;       // :96-97
   return DDDMR_OK;
 }
 

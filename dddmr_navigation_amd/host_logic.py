@@ -12,18 +12,10 @@ from typing import Optional
 import numpy as np
 
 
-def prune_plan(global_plan: np.ndarray, robot_xyz, forward_distance: float, backward_distance: float) -> Optional[np.ndarray]:
-    """Local_Planner::prunePlan (local_planner.cpp:374-445).
-
-    global_plan: [G,7] poses (x y z qx qy qz qw).  Returns the prune plan [M,7], or
-    None where the reference returns without touching prune_plan_ (fewer than 3
-    poses :376-377, or the robot is more than 1 m off the plan :395-399).
-
-    Quirk kept on purpose: the nearest pose is pushed twice (once by the backward
-    walk, once by the forward walk, :404 and :421).  Both walks stop at the first
-    pose whose accumulated distance EXCEEDS the budget (that pose is included).
-    """
-    plan = np.ascontiguousarray(global_plan, dtype=np.float64).reshape(-1, 7)
+def _prune_walk(plan: np.ndarray, robot_xyz, forward_distance: float, backward_distance: float):
+    """The two walks of Local_Planner::prunePlan (local_planner.cpp:374-445) as global-plan
+    indices: (backward walk in walk order idx, idx-1, ...; forward walk idx, idx+1, ...),
+    or None where the reference returns early."""
     if len(plan) < 3:
         return None
     # 1-NN on the float point cloud of the plan with FLANN's float distance (:389)
@@ -40,26 +32,64 @@ def prune_plan(global_plan: np.ndarray, robot_xyz, forward_distance: float, back
     def dist(a, b):
         return math.sqrt((a[0] - b[0]) ** 2 + (a[1] - b[1]) ** 2 + (a[2] - b[2]) ** 2)
 
-    out = []
+    back, fwd = [], []
     last = plan[idx]
     bd = backward_distance
     for i in range(idx, -1, -1):            # backward check (:403-415)
-        out.append(plan[i])
+        back.append(i)
         if i < idx:
             bd -= dist(last, plan[i])
         last = plan[i]
         if bd < 0:
             break
-    out.reverse()
     fd = forward_distance
     for i in range(idx, len(plan)):          # forward check (:420-438); last := plan[idx] at i == idx (:435)
-        out.append(plan[i])
+        fwd.append(i)
         if i > idx:
             fd -= dist(last, plan[i])
         last = plan[i]
         if fd < 0:
             break
-    return np.array(out, dtype=np.float64)
+    return back, fwd
+
+
+def prune_plan(global_plan: np.ndarray, robot_xyz, forward_distance: float, backward_distance: float) -> Optional[np.ndarray]:
+    """Local_Planner::prunePlan (local_planner.cpp:374-445).
+
+    global_plan: [G,7] poses (x y z qx qy qz qw).  Returns the prune plan [M,7], or
+    None where the reference returns without touching prune_plan_ (fewer than 3
+    poses :376-377, or the robot is more than 1 m off the plan :395-399).
+
+    Quirk kept on purpose: the nearest pose is pushed twice (once by the backward
+    walk, once by the forward walk, :404 and :421).  Both walks stop at the first
+    pose whose accumulated distance EXCEEDS the budget (that pose is included).
+    """
+    plan = np.ascontiguousarray(global_plan, dtype=np.float64).reshape(-1, 7)
+    w = _prune_walk(plan, robot_xyz, forward_distance, backward_distance)
+    if w is None:
+        return None
+    back, fwd = w
+    return plan[back[::-1] + fwd].copy()       # std::reverse of the backward part (:417), then the forward part
+
+
+def prune_plan_cloud(global_plan: np.ndarray, robot_xyz, forward_distance: float, backward_distance: float):
+    """pcl_prune_plan_ as Local_Planner::prunePlan fills it next to prune_plan_
+    (local_planner.cpp:402-430): [M,4] float32 x y z intensity -- the backward walk's
+    points in walk order tagged -1, then the forward walk's points tagged 1 (0 for plan
+    index 0).  Unlike prune_plan_.poses it is NOT reversed (:417 reverses the poses only).
+    PathBlockedStrategy reads the tag (path_blocked_strategy.cpp:80).  None where the
+    reference returns early."""
+    plan = np.ascontiguousarray(global_plan, dtype=np.float64).reshape(-1, 7)
+    w = _prune_walk(plan, robot_xyz, forward_distance, backward_distance)
+    if w is None:
+        return None
+    back, fwd = w
+    out = np.zeros((len(back) + len(fwd), 4), dtype=np.float32)
+    out[: len(back), :3] = plan[back, :3]
+    out[: len(back), 3] = -1.0
+    out[len(back):, :3] = plan[fwd, :3]
+    out[len(back):, 3] = [0.0 if i == 0 else 1.0 for i in fwd]
+    return out
 
 
 def is_goal_reached(global_plan: np.ndarray, robot_xyz, xy_goal_tolerance: float) -> bool:

@@ -140,6 +140,18 @@ class LocalPlanner:
 
     set_prune_plan = setPlan
 
+    def path_blocked(self, pcl_prune_plan: np.ndarray, check_radius: float):
+        """PathBlockedStrategy::selfMark (path_blocked_strategy.cpp:56-100) on the current
+        aggregate observation.  pcl_prune_plan: [M,4] x y z intensity as prunePlan fills it
+        (host_logic.prune_plan_cloud).  -> (blocked ratio in percent, opinion, flags[M])"""
+        plan = np.ascontiguousarray(pcl_prune_plan, dtype=np.float32).reshape(-1, 4)
+        flags = np.zeros(max(len(plan), 1), dtype=np.uint8)
+        ratio, op = C.c_double(0.0), C.c_int32(0)
+        self._check(self._lib.dddmr_rollout_path_blocked(self._ctx, plan.ctypes.data_as(C.c_void_p), len(plan),
+                                                         float(check_radius), C.byref(ratio), C.byref(op),
+                                                         flags.ctypes.data_as(C.c_void_p)))
+        return ratio.value, op.value, flags[: len(plan)].astype(bool)
+
     # -- the tick ----------------------------------------------------------
     def tick(self, traj_gen_name: str, tick_in: K.TickInput) -> K.RolloutResult:
         res = K.RolloutResult()

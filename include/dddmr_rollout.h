@@ -234,6 +234,25 @@ int dddmr_rollout_get_cloud(dddmr_rollout_ctx* ctx, float* xyzi_out, size_t capa
 int dddmr_rollout_set_prune_plan(dddmr_rollout_ctx* ctx, const double* poses_xyz_qxyzw,
                                  size_t n_poses);
 
+/* Perception opinions (dddmr_perception_3d/include/perception_3d/sensor.h, PerceptionOpinion). */
+typedef enum {
+  DDDMR_OPINION_PASS = 0,
+  DDDMR_OPINION_PATH_BLOCKED_WAIT = 1
+} dddmr_perception_opinion;
+
+/* PathBlockedStrategy::selfMark
+   (dddmr_perception_3d/plugins/path_blocked_strategy.cpp:56-100) on the current aggregate
+   observation: plan_xyzi is pcl_prune_plan_ as Local_Planner::prunePlan fills it
+   (local_planner.cpp:402-430: n_points records x,y,z,intensity, backward points tagged
+   intensity < 0).  *blocked_ratio_percent = blocked forward points / n_points * 100,
+   *opinion = PATH_BLOCKED_WAIT when that is > 0 (computeVelocityCommand then returns
+   dddmr_sys_core::PATH_BLOCKED_WAIT, local_planner.cpp:597-602).  blocked_flags (may be
+   NULL) receives one byte per plan point.  Replaces the second per-tick kd-tree build on
+   the observation (:68-70). */
+int dddmr_rollout_path_blocked(dddmr_rollout_ctx* ctx, const float* plan_xyzi, size_t n_points,
+                               double check_radius, double* blocked_ratio_percent, int32_t* opinion,
+                               uint8_t* blocked_flags);
+
 /* One control tick for the named theory. */
 int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name,
                        const dddmr_tick_input* in, dddmr_rollout_result* out);

@@ -122,6 +122,18 @@ class LocalPlanner {
     return poses;
   }
 
+  // PathBlockedStrategy::selfMark (path_blocked_strategy.cpp:56-100) on the current
+  // aggregate observation; pcl_prune_plan: x y z intensity records as prunePlan fills
+  // them (local_planner.cpp:402-430).  Returns prune_plan_blocked_ratio_ (percent).
+  double pathBlockedRatio(const float* pcl_prune_plan_xyzi, size_t n_points, double check_radius,
+                          dddmr_perception_opinion* opinion = nullptr) {
+    double ratio = 0.0;
+    int32_t op = DDDMR_OPINION_PASS;
+    check(dddmr_rollout_path_blocked(ctx_, pcl_prune_plan_xyzi, n_points, check_radius, &ratio, &op, nullptr));
+    if (opinion) *opinion = static_cast<dddmr_perception_opinion>(op);
+    return ratio;
+  }
+
  private:
   void check(int rc) {
     if (rc != DDDMR_OK) throw RolloutError(rc, dddmr_rollout_last_error(ctx_));

@@ -438,9 +438,12 @@ class KdTree {
   // radiusSearch: all points with dist^2 < r^2 (FLANN RadiusResultSet::addPoint
   // uses a strict comparison; unverified offline -- fixtures stay away from it).
   int radius_search(const float q[3], float radius, std::vector<int>& out) const {
+    return radius_search_r2(q, radius * radius, out);
+  }
+  // same with the squared radius given (PCL: static_cast<float>(radius * radius) of a double radius)
+  int radius_search_r2(const float q[3], float r2, std::vector<int>& out) const {
     out.clear();
     if (nodes_.empty()) return 0;
-    const float r2 = radius * radius;
     radius_rec(0, q, r2, out);
     return (int)out.size();
   }
@@ -798,6 +801,42 @@ int oracle_radius_count(const float* xyz, size_t n_points, size_t stride_bytes, 
   kd.build(xyz, n_points, stride_bytes / sizeof(float));
   std::vector<int> id;
   for (size_t i = 0; i < n_queries; ++i) counts[i] = kd.radius_search(q + 3 * i, radius, id);
+  return 0;
+}
+
+// --------------------------------------------------------------------------
+// PathBlockedStrategy::selfMark
+// (dddmr_perception_3d/plugins/path_blocked_strategy.cpp:56-100): the share of the
+// prune-plan cloud (pcl_prune_plan_, local_planner.cpp:402-430: backward points tagged
+// intensity -1, forward points 0 / 1) whose FORWARD points have an observation point
+// within check_radius.  A fresh kd-tree on the aggregate observation (:68-70);
+// pcl::KdTreeFLANN::radiusSearch(point, double radius) hands
+// static_cast<float>(radius * radius) to FLANN.  blocked / size are floats, * 100.0
+// in double (:91-93).  opinion: 0 = PASS, 1 = PATH_BLOCKED_WAIT (:96-97).
+// --------------------------------------------------------------------------
+int oracle_path_blocked(const float* cloud, size_t n_points, size_t stride_bytes, const float* plan_xyzi,
+                        size_t n_plan, double check_radius, double* ratio, int32_t* opinion,
+                        uint8_t* blocked_flags) {
+  *ratio = 0.0;
+  *opinion = 0;
+  if (blocked_flags) std::memset(blocked_flags, 0, n_plan);
+  if (n_points <= 5 || n_plan == 0) return 0;                       // :62-64
+  KdTree kd;
+  kd.build(cloud, n_points, stride_bytes / sizeof(float));
+  const float r2 = static_cast<float>(check_radius * check_radius);
+  std::vector<int> id;
+  size_t blocked = 0;
+  for (size_t i = 0; i < n_plan; ++i) {
+    const float* p = plan_xyzi + 4 * i;
+    if (p[3] < 0) continue;                                         // :80-81
+    if (kd.radius_search_r2(p, r2, id) > 0) {                       // :83
+      ++blocked;
+      if (blocked_flags) blocked_flags[i] = 1;
+    }
+  }
+  const float orig = (float)n_plan, blk = (float)blocked;           // :91-92
+  *ratio = (blk) / (orig) * 100.0;                                  // :93
+  if (*ratio > 0.0) *opinion = 1;
   return 0;
 }
 

@@ -40,6 +40,9 @@ int oracle_generate(const dddmr_theory_config* theory, const dddmr_tick_input* i
                     int capacity);
 int oracle_radius_count(const float* xyz, size_t n_points, size_t stride_bytes, const float* q,
                         size_t n_queries, float radius, int32_t* counts);
+int oracle_path_blocked(const float* cloud, size_t n_points, size_t stride_bytes, const float* plan_xyzi,
+                        size_t n_plan, double check_radius, double* ratio, int32_t* opinion,
+                        uint8_t* blocked_flags);
 int oracle_tick(const dddmr_theory_config* theory, const float* cloud, size_t n_points,
                 size_t stride_bytes, const double* plan, size_t n_plan,
                 const dddmr_tick_input* in, uint32_t begin, uint32_t end, int n_threads,

@@ -51,6 +51,9 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     lib.oracle_radius_count.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t,
                                         C.c_float, C.c_void_p]
     lib.oracle_radius_count.restype = C.c_int
+    lib.oracle_path_blocked.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double,
+                                        C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p]
+    lib.oracle_path_blocked.restype = C.c_int
     lib.oracle_tick.argtypes = [C.POINTER(K.TheoryConfig), C.c_void_p, C.c_size_t, C.c_size_t,
                                 C.c_void_p, C.c_size_t, C.POINTER(K.TickInput), C.c_uint32, C.c_uint32,
                                 C.c_int, C.POINTER(OracleResult), C.c_void_p, C.c_void_p, C.c_void_p,
@@ -101,6 +104,21 @@ def radius_count(cloud_xyz: np.ndarray, queries: np.ndarray, radius: float) -> n
     counts = np.zeros(len(q), dtype=np.int32)
     lib.oracle_radius_count(_ptr(cloud), cloud.shape[0], cloud.strides[0], _ptr(q), len(q), radius, _ptr(counts))
     return counts
+
+
+def path_blocked(cloud: np.ndarray, plan_xyzi: np.ndarray, check_radius: float):
+    """PathBlockedStrategy::selfMark -> (blocked ratio in percent, opinion 0/1, per-point flags)."""
+    lib = load()
+    cloud = np.ascontiguousarray(cloud, dtype=np.float32)
+    if cloud.ndim != 2:
+        cloud = cloud.reshape(-1, 4)
+    plan = np.ascontiguousarray(plan_xyzi, dtype=np.float32).reshape(-1, 4)
+    flags = np.zeros(max(len(plan), 1), dtype=np.uint8)
+    ratio, op = C.c_double(0.0), C.c_int32(0)
+    stride = cloud.strides[0] if len(cloud) else 16
+    lib.oracle_path_blocked(_ptr(cloud), cloud.shape[0], stride, _ptr(plan), len(plan), float(check_radius),
+                            C.byref(ratio), C.byref(op), _ptr(flags))
+    return ratio.value, op.value, flags[: len(plan)].astype(bool)
 
 
 @dataclass

@@ -52,6 +52,14 @@ int main(int argc, char** argv) {
     const auto poses = lp.bestPoses();
     std::printf("%d %d %.17g %.17g %.17g %.17g %u %zu\n", (int)st, best.index_, best.cost_, best.xv_, best.yv_, best.thetav_,
                 lp.lastResult().n_samples, poses.size());
+    // PathBlockedStrategy: 6 observation points (one more than the "no obstacle" rule) next to the
+    // third of four plan points, the first one tagged backward
+    float cloud6[6][8] = {{1.0f, 0.05f, 0.f}, {1.0f, 0.05f, 0.f}, {1.0f, 0.05f, 0.f}, {1.0f, 0.05f, 0.f}, {1.0f, 0.05f, 0.f}, {1.0f, 0.05f, 0.f}};
+    lp.setCloud(&cloud6[0][0], 6, 32);
+    const float pcl_prune_plan[4][4] = {{0.f, 0.f, 0.f, -1.f}, {0.5f, 0.f, 0.f, 1.f}, {1.0f, 0.f, 0.f, 1.f}, {1.5f, 0.f, 0.f, 1.f}};
+    dddmr_perception_opinion op = DDDMR_OPINION_PASS;
+    const double ratio = lp.pathBlockedRatio(&pcl_prune_plan[0][0], 4, 0.2, &op);
+    std::printf("blocked %.17g %d\n", ratio, (int)op);
     dddmr_amd::Trajectory none;
     try {
       lp.computeVelocityCommand("no_such_theory", none, in);

@@ -29,4 +29,6 @@ def test_cpp_playground_matches_oracle(tmp_path, goal):
     assert abs(float(cost) - r.best_cost) <= 1e-4
     assert abs(float(vx) - r.vx) <= 1e-4 and abs(float(vy) - r.vy) <= 1e-4 and abs(float(wz) - r.wz) <= 1e-4
     assert int(nposes) == int(o.steps[r.best_index])
-    assert out[1].strip() == f"error {K.ERR_UNKNOWN_THEORY}"
+    tag, ratio, op = out[1].split()
+    assert tag == "blocked" and float(ratio) == 25.0 and int(op) == K.OPINION_PATH_BLOCKED_WAIT
+    assert out[2].strip() == f"error {K.ERR_UNKNOWN_THEORY}"

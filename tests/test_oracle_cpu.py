@@ -307,3 +307,32 @@ def test_feed_oracle_voxel_centroids():
     out = out[np.argsort(out[:, 0])]
     np.testing.assert_allclose(out[0], [11.02, 0.02, 1.02], atol=1e-6)
     np.testing.assert_allclose(out[1], [11.25, 0.0, 1.0], atol=1e-6)
+
+
+def test_path_blocked_known_answers():
+    """PathBlockedStrategy::selfMark by hand (path_blocked_strategy.cpp:56-100)."""
+    pc = np.array([[0, 0, 0, -1], [0.5, 0, 0, 1], [1.0, 0, 0, 1], [1.5, 0, 0, 1]], np.float32)
+    few = np.array([[0.5, 0, 0, 0]] * 5, np.float32)
+    assert oracle.path_blocked(few, pc, 0.3)[:2] == (0.0, 0)                  # <= 5 points: ratio 0
+    six = np.array([[0.5, 0.1, 0, 0]] * 6, np.float32)
+    ratio, op, flags = oracle.path_blocked(six, pc, 0.3)
+    assert flags.tolist() == [False, True, False, False] and op == 1
+    assert ratio == float(np.float32(1) / np.float32(4)) * 100.0              # float division, double scale
+    ratio, op, flags = oracle.path_blocked(six, pc, 0.6)                        # reaches 0.0 too, but that one is backward
+    assert flags.tolist() == [False, True, True, False]
+    far = np.array([[0.0, 0.05, 0, 0]] * 6, np.float32)
+    assert oracle.path_blocked(far, pc, 0.2)[:2] == (0.0, 0)                   # only near the backward point
+    edge = np.array([[0.75, 0, 0, 0]] * 6, np.float32)
+    assert oracle.path_blocked(edge, pc, 0.25)[1] == 0                          # dist^2 == r^2 is outside (strict <)
+    # brute force cross-check on random data
+    rng = np.random.default_rng(0)
+    cloud = np.zeros((3000, 4), np.float32); cloud[:, :3] = rng.uniform(-3, 3, (3000, 3))
+    plan = np.zeros((60, 4), np.float32); plan[:, :3] = rng.uniform(-3, 3, (60, 3)); plan[:, 3] = rng.choice([-1, 1], 60)
+    r = 0.35
+    _, _, flags = oracle.path_blocked(cloud, plan, r)
+    d = plan[:, None, :3] - cloud[None, :, :3]
+    d2 = (d[..., 0] * d[..., 0]).astype(np.float32)
+    d2 = (d2 + d[..., 1] * d[..., 1]).astype(np.float32)
+    d2 = (d2 + d[..., 2] * d[..., 2]).astype(np.float32)
+    want = (d2 < np.float32(r * r)).any(axis=1) & (plan[:, 3] >= 0)
+    np.testing.assert_array_equal(flags, want)
