@@ -159,6 +159,7 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_resolve",
     "dddmr_rollout_get_debug",
     "dddmr_rollout_get_best_poses",
+    "dddmr_rollout_get_pose_arrays",
     "dddmr_rollout_path_blocked",
     "dddmr_rollout_pack_key",
     "dddmr_rollout_key_index",
@@ -215,6 +216,8 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_get_debug.restype = C.c_int
     lib.dddmr_rollout_get_best_poses.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.dddmr_rollout_get_best_poses.restype = C.c_int
+    lib.dddmr_rollout_get_pose_arrays.argtypes = [ctx_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.dddmr_rollout_get_pose_arrays.restype = C.c_int
     lib.dddmr_rollout_path_blocked.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.c_double, C.POINTER(C.c_double),
                                                C.POINTER(C.c_int32), C.c_void_p]
     lib.dddmr_rollout_path_blocked.restype = C.c_int

@@ -1103,6 +1103,56 @@ int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg) {
   return DDDMR_OK;
 }
 
+int dddmr_rollout_get_pose_arrays(dddmr_rollout_ctx* ctx, int32_t which, double* poses_out, size_t capacity,
+                                  size_t* n_poses) {
+  if (!ctx || !n_poses || (which != 0 && which != 1)) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (!ctx->have_last) return fail(ctx, DDDMR_ERR_STATE, "get_pose_arrays before any tick");
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "get_pose_arrays while a tick_begin is pending");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const int n = ctx->last.n_local;
+  *n_poses = 0;
+  if (n <= 0) return DDDMR_OK;
+  std::vector<int32_t> steps(n), off(n);
+  std::vector<double> costs(n);
+  HIPCHK(ctx, hipMemcpy(steps.data(), ctx->steps, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(costs.data(), ctx->costs, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    // generated: nextTrajectory returned true (steps > 0); accepted: cost_ >= 0 (local_planner.cpp:463)
+    const bool want = steps[i] > 0 && (which == 0 || costs[i] >= 0.0);
+    off[i] = want ? (int32_t)total : -1;
+    if (want) total += (size_t)steps[i];
+  }
+  *n_poses = total;
+  if (!poses_out || total == 0) return DDDMR_OK;
+  if (capacity < total) return fail(ctx, DDDMR_ERR_CAPACITY, "get_pose_arrays: capacity %zu < %zu", capacity, total);
+  if (total > (size_t)INT32_MAX) return fail(ctx, DDDMR_ERR_CAPACITY, "get_pose_arrays: %zu poses", total);
+  int32_t* off_dev = nullptr;
+  double* out_dev = nullptr;
+  HIPCHK(ctx, hipMalloc(&off_dev, (size_t)n * sizeof(int32_t)));
+  if (hipMalloc(&out_dev, total * 7 * sizeof(double)) != hipSuccess) {
+    (void)hipFree(off_dev);
+    return fail(ctx, DDDMR_ERR_HIP, "get_pose_arrays: out of device memory for %zu poses", total);
+  }
+  int rc = DDDMR_OK;
+  const size_t pairs = (size_t)n * (size_t)ctx->last.max_steps;
+  if (hipMemcpyAsync(off_dev, off.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    rc = DDDMR_ERR_HIP;
+  if (rc == DDDMR_OK) {
+    hipLaunchKernelGGL(k_pose_arrays, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, ctx->stream, ctx->last, off_dev,
+                       ctx->steps, ctx->st_sc, ctx->st_xy, out_dev);
+    if (hipMemcpyAsync(poses_out, out_dev, total * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess)
+      rc = DDDMR_ERR_HIP;
+  }
+  (void)hipFree(off_dev);
+  (void)hipFree(out_dev);
+  if (rc != DDDMR_OK) return fail(ctx, rc, "get_pose_arrays: %s", hipGetErrorString(hipGetLastError()));
+  return DDDMR_OK;
+}
+
 int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out, size_t capacity, size_t* n_poses) {
   if (!ctx || !n_poses) return DDDMR_ERR_BAD_ARG;
   std::lock_guard<std::mutex> tk(ctx->tick_mu);

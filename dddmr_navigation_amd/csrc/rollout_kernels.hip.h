@@ -1400,6 +1400,33 @@ __global__ void k_empty_result(DevTick k, const uint32_t* __restrict__ cell_star
   __hip_atomic_store(&res->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// position + Eigen::Quaterniond(T.linear()) of one pose -> x y z qx qy qz qw
+__device__ __forceinline__ void write_pose(const double L[9], const double T[3], double* o) {
+  double q[4];  // x y z w
+  double tr = L[0] + L[4] + L[8];
+  if (tr > 0.0) {
+    double t = sqrt(tr + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (L[7] - L[5]) * t;
+    q[1] = (L[2] - L[6]) * t;
+    q[2] = (L[3] - L[1]) * t;
+  } else {
+    int i = 0;
+    if (L[4] > L[0]) i = 1;
+    if (L[8] > L[4 * i]) i = 2;
+    const int j = (i + 1) % 3, kk = (j + 1) % 3;
+    double t = sqrt(L[4 * i] - L[4 * j] - L[4 * kk] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (L[3 * kk + j] - L[3 * j + kk]) * t;
+    q[j] = (L[3 * j + i] + L[3 * i + j]) * t;
+    q[kk] = (L[3 * kk + i] + L[3 * i + kk]) * t;
+  }
+  o[0] = T[0]; o[1] = T[1]; o[2] = T[2];
+  o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
+}
+
 // Poses of one trajectory for visualisation (local_planner.cpp:472-478 publishes
 // the best trajectory): position + Quaterniond(T.linear()) per step, recomputed
 // by one lane with the same recurrence as k_score.
@@ -1435,32 +1462,32 @@ __global__ void k_trajectory_poses(DevTick k, int li, const float4* __restrict__
       L[3 * i + 2] = r2;
       T[i] = r0 * (double)px + r1 * (double)py + k.t[i];
     }
-    // Eigen::Quaterniond(matrix)
-    double q[4];  // x y z w
-    double tr = L[0] + L[4] + L[8];
-    if (tr > 0.0) {
-      double t = sqrt(tr + 1.0);
-      q[3] = 0.5 * t;
-      t = 0.5 / t;
-      q[0] = (L[7] - L[5]) * t;
-      q[1] = (L[2] - L[6]) * t;
-      q[2] = (L[3] - L[1]) * t;
-    } else {
-      int i = 0;
-      if (L[4] > L[0]) i = 1;
-      if (L[8] > L[4 * i]) i = 2;
-      const int j = (i + 1) % 3, kk = (j + 1) % 3;
-      double t = sqrt(L[4 * i] - L[4 * j] - L[4 * kk] + 1.0);
-      q[i] = 0.5 * t;
-      t = 0.5 / t;
-      q[3] = (L[3 * kk + j] - L[3 * j + kk]) * t;
-      q[j] = (L[3 * j + i] + L[3 * i + j]) * t;
-      q[kk] = (L[3 * kk + i] + L[3 * i + kk]) * t;
-    }
-    double* o = poses + 7 * (size_t)s;
-    o[0] = T[0]; o[1] = T[1]; o[2] = T[2];
-    o[3] = q[0]; o[4] = q[1]; o[5] = q[2]; o[6] = q[3];
+    write_pose(L, T, poses + 7 * (size_t)s);
   }
+}
+
+// Pose arrays of many trajectories at once (the reference's `trajectory` and
+// `accepted_trajectory` debug topics, local_planner.cpp:549-569 and :447-470): one lane
+// per (trajectory, step) straight from the rollout state of the last tick; off[li] is
+// the first output pose of trajectory li, or -1 when it is not wanted.
+__global__ __launch_bounds__(256) void k_pose_arrays(DevTick k, const int32_t* __restrict__ off,
+                                                     const int32_t* __restrict__ steps,
+                                                     const double2* __restrict__ st_sc, const float2* __restrict__ st_xy,
+                                                     double* __restrict__ poses) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int li = (int)(idx / (size_t)k.max_steps), s = (int)(idx % (size_t)k.max_steps);
+  if (li >= k.n_local || s >= steps[li] || off[li] < 0) return;
+  const double2 cs = st_sc[idx];
+  const float2 bxy = st_xy[idx];
+  double L[9], T[3];
+  for (int i = 0; i < 3; ++i) {
+    const double r0 = k.R[3 * i + 0], r1 = k.R[3 * i + 1], r2 = k.R[3 * i + 2];
+    L[3 * i + 0] = r0 * cs.x + r1 * cs.y;
+    L[3 * i + 1] = r1 * cs.x - r0 * cs.y;
+    L[3 * i + 2] = r2;
+  }
+  pose_translation(k, bxy, T);
+  write_pose(L, T, poses + 7 * ((size_t)off[li] + (size_t)s));
 }
 
 }  // namespace dddmr

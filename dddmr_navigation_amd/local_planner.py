@@ -199,6 +199,16 @@ class LocalPlanner:
         self._check(self._lib.dddmr_rollout_get_debug(self._ctx, C.byref(dbg)))
         return costs[:n], steps[:n], smp[:n]
 
+    def pose_arrays(self, accepted_only: bool = False) -> np.ndarray:
+        """The `trajectory` / `accepted_trajectory` debug pose arrays of the last tick, [n,7]."""
+        which = 1 if accepted_only else 0
+        n = C.c_size_t(0)
+        self._check(self._lib.dddmr_rollout_get_pose_arrays(self._ctx, which, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 7), dtype=np.float64)
+        self._check(self._lib.dddmr_rollout_get_pose_arrays(self._ctx, which, out.ctypes.data_as(C.c_void_p), out.shape[0],
+                                                            C.byref(n)))
+        return out[: n.value]
+
     def best_poses(self) -> np.ndarray:
         n = C.c_size_t(0)
         self._check(self._lib.dddmr_rollout_get_best_poses(self._ctx, None, 0, C.byref(n)))

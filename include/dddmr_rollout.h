@@ -275,6 +275,15 @@ int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key,
 /* Per-trajectory outputs of the last tick (any pointer may be NULL). */
 int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg);
 
+/* Debug pose arrays of the last tick, poses_out[n][7] x y z qx qy qz qw, trajectory by
+   trajectory in sample order, poses in step order: which = 0 the `trajectory` topic
+   (every generated trajectory, local_planner.cpp:549-569), which = 1 the
+   `accepted_trajectory` topic (cost_ >= 0, local_planner.cpp:461-470).  Call with
+   poses_out == NULL to get the count.  Computed on demand from the rollout state the
+   tick left on the device; nothing is copied unless this is called. */
+int dddmr_rollout_get_pose_arrays(dddmr_rollout_ctx* ctx, int32_t which, double* poses_out,
+                                  size_t capacity, size_t* n_poses);
+
 /* Best trajectory poses of the last tick for visualisation
    (local_planner.cpp:472-478): poses_out[n][7] x y z qx qy qz qw. */
 int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out,

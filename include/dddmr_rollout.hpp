@@ -122,6 +122,15 @@ class LocalPlanner {
     return poses;
   }
 
+  // `trajectory` (accepted_only = false) / `accepted_trajectory` debug pose arrays
+  std::vector<std::array<double, 7>> poseArrays(bool accepted_only) {
+    size_t n = 0;
+    check(dddmr_rollout_get_pose_arrays(ctx_, accepted_only ? 1 : 0, nullptr, 0, &n));
+    std::vector<std::array<double, 7>> poses(n);
+    if (n) check(dddmr_rollout_get_pose_arrays(ctx_, accepted_only ? 1 : 0, &poses[0][0], n, &n));
+    return poses;
+  }
+
   // PathBlockedStrategy::selfMark (path_blocked_strategy.cpp:56-100) on the current
   // aggregate observation; pcl_prune_plan: x y z intensity records as prunePlan fills
   // them (local_planner.cpp:402-430).  Returns prune_plan_blocked_ratio_ (percent).

@@ -249,6 +249,50 @@ def test_host_mirror_compute_velocity_command_and_poses():
         np.testing.assert_allclose(poses, ref, atol=1e-5)
 
 
+@pytest.mark.parametrize("cfg", ["playground", "omni"])
+def test_debug_pose_arrays_match_oracle(cfg):
+    """`trajectory` (every generated trajectory, local_planner.cpp:549-569) and
+    `accepted_trajectory` (cost >= 0, :461-470) pose arrays: per-trajectory poses of the
+    oracle's generateTrajectory, concatenated in sample order."""
+    if cfg == "playground":
+        sc = scenes.playground_scene()
+        th, cloud, plan, tick = sc.theory, sc.cloud, sc.plan, sc.tick
+    else:
+        sc = scenes.bench_scene("C1")
+        th = configs.omni_simple_shipped(linear_x_sample=4.0, linear_y_sample=3.0, angular_z_sample=5.0)
+        cloud, plan = sc.cloud, sc.plan
+        post = np.array([[0.9, 0.1, 0.3, 0]] * 8, np.float32)
+        cloud = np.concatenate([cloud, post])
+        tick = scenes.tick_input(pose=(0.2, -0.1, 0.0) + scenes.quat_from_rpy(0.02, -0.03, 0.4), twist=(0.3, 0.1, 0.1))
+    name = th.name.decode()
+    with LocalPlanner([th], max_points=max(len(cloud), 16)) as lp:
+        lp.set_cloud(cloud)
+        lp.setPlan(plan)
+        lp.tick(name, tick)
+        costs, steps, smp = (a.copy() for a in lp.debug())
+        every = lp.pose_arrays()
+        accepted = lp.pose_arrays(accepted_only=True)
+        best = lp.best_poses()
+    o = oracle.tick(th, cloud, plan, tick)
+    want_all, want_acc = [], []
+    for i in range(len(steps)):
+        if steps[i] <= 0:
+            continue
+        ref, _, _ = oracle.generate(th, tick, o.samples[i])
+        assert len(ref) == steps[i]
+        want_all.append(ref)
+        if o.costs[i] >= 0:
+            want_acc.append(ref)
+    assert (costs >= 0).any() and (costs < 0).any()
+    np.testing.assert_allclose(every, np.concatenate(want_all), atol=1e-5)
+    np.testing.assert_allclose(accepted, np.concatenate(want_acc), atol=1e-5)
+    assert len(every) == steps[steps > 0].sum() > len(accepted) > 0
+    # the best trajectory's poses are a slice of the accepted array
+    bi = o.result.best_index
+    start = int(sum(steps[i] for i in range(bi) if costs[i] >= 0))
+    np.testing.assert_allclose(accepted[start:start + steps[bi]], best, atol=1e-12)
+
+
 def test_tick_begin_end_equals_tick_and_guards_state():
     sc = scenes.bench_scene("C1")
     name = sc.theory.name.decode()
