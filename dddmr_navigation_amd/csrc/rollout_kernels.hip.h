@@ -939,11 +939,14 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       for (int a = 0; a < 3; ++a) {
         const float ex = fsub(v[vi[a]][0], v[0][0]), ey = fsub(v[vi[a]][1], v[0][1]), ez = fsub(v[vi[a]][2], v[0][2]);
         const float len = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
-        const double h = (double)len / 2.;
-        r[12 + a] = (float)h;                    // len/2 is exact in float
-        r[3 + 3 * a + 0] = (float)((double)ex / (2. * h));
-        r[3 + 3 * a + 1] = (float)((double)ey / (2. * h));
-        r[3 + 3 * a + 2] = (float)((double)ez / (2. * h));
+        // The reference divides in double, (float)((double)e / (2. * h)) with h = (double)len / 2.:
+        // 2h == len exactly, and rounding a double quotient of two floats to float equals
+        // the correctly rounded float division (53 >= 2*24 + 2 bits: double rounding is
+        // innocuous for division) -- so the IEEE float divide gives the same bits for less.
+        r[12 + a] = len * 0.5f;                  // len/2 is exact in float
+        r[3 + 3 * a + 0] = ex / len;
+        r[3 + 3 * a + 1] = ey / len;
+        r[3 + 3 * a + 2] = ez / len;
       }
       // candidate cells: cuboid AABB clipped to the 1 m search ball's AABB
       const float lox = fmaxf(mnx, px - 1.0f), hix = fminf(mxx, px + 1.0f);
