@@ -803,6 +803,18 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   for (int i = 0; i < 3; ++i) k.gmin[i] = k.rmin[i];
   // rows <= floor(span / cell) + 2 (span = cuboid diameter clipped to the 2 m search ball)
   k.rows_cap = std::min(kRows, (int)std::floor(std::min(diam, 2.0) * 1.001 / cell) + 2);
+  {
+    // box in the body frame, vertices in the push order blb brb blt flb brt frt flt frb
+    // (dd_simple_trajectory_generator_theory.cpp:211-218)?  Then k_score shares the products.
+    const float (*c)[3] = th->cuboid;
+    const float X0 = c[0][0], X1 = c[3][0], Y0 = c[0][1], Y1 = c[1][1], Z0 = c[0][2], Z1 = c[2][2];
+    const float want[8][3] = {{X0, Y0, Z0}, {X0, Y1, Z0}, {X0, Y0, Z1}, {X1, Y0, Z0},
+                              {X0, Y1, Z1}, {X1, Y1, Z1}, {X1, Y0, Z1}, {X1, Y1, Z0}};
+    bool box = true;
+    for (int v = 0; v < 8; ++v)
+      for (int a = 0; a < 3; ++a) box = box && (c[v][a] == want[v][a]);
+    k.box_fast = (box && !std::getenv("DDDMR_NO_BOXFAST")) ? 1 : 0;
+  }
 
   // trajectories per workgroup: ~one (trajectory, step) pair per lane
   // OBB records carry the pose only if some pair can need the 1 m radius test: a point

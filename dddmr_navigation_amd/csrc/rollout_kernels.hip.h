@@ -98,6 +98,7 @@ struct DevTick {
   int rt;            // trajectories per rollout workgroup
   int bin_blocks;    // binning workgroups of the k_bin_count launch, followed by
   int roll_blocks;   // the rollout workgroups and (use_assign) one assignment workgroup
+  int box_fast;      // the cuboid is a body-frame box in the reference's vertex order (host-checked)
   int rec_pose;      // OBB records carry the pose (some pair may need the 1 m radius test, or min-max critic)
   uint32_t seq;      // tick sequence number echoed into DevResult::seq
   float axes_inl[kInlineAxes];
@@ -925,12 +926,39 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
           vmax2 = fmaxf(vmax2, ux * ux + uy * uy + uz * uz);
         }
       };
+      if (k.box_fast && !k.rec_pose) {
+        // The cuboid is a box in the body frame (x back/front, y left/right, z bottom/top --
+        // checked bit for bit on the host), so the 24 products L(i,c) * coordinate take only
+        // 18 distinct values and the partial sums L(i,0) x + L(i,1) y only 12: same
+        // operations in the same order as the general path, each done once.
+        // vertex order blb brb blt flb brt frt flt frb -> (x, y, z) selectors
+        //   0:(0,0,0) 1:(0,1,0) 2:(0,0,1) 3:(1,0,0) 4:(0,1,1) 5:(1,1,1) 6:(1,0,1) 7:(1,1,0)
+        const double X0 = k.cub[0], X1 = k.cub[9], Y0 = k.cub[1], Y1 = k.cub[4], Z0 = k.cub[2], Z1 = k.cub[8];
+        auto row = [&](const int i, float& mn, float& mx, float& cc, float& v0, float& v1, float& v2, float& v3) {
+          const double a0 = L[3 * i] * X0, a1 = L[3 * i] * X1;
+          const double b0 = L[3 * i + 1] * Y0, b1 = L[3 * i + 1] * Y1;
+          const double c0 = L[3 * i + 2] * Z0, c1 = L[3 * i + 2] * Z1;
+          const double s00 = a0 + b0, s01 = a0 + b1, s10 = a1 + b0, s11 = a1 + b1;
+          const double t = T[i];
+          const float w0 = (float)((s00 + c0) + t), w1 = (float)((s01 + c0) + t), w2 = (float)((s00 + c1) + t),
+                      w3 = (float)((s10 + c0) + t), w4 = (float)((s01 + c1) + t), w5 = (float)((s11 + c1) + t),
+                      w6 = (float)((s10 + c1) + t), w7 = (float)((s11 + c0) + t);
+          mn = fminf(fminf(fminf(w0, w1), fminf(w2, w3)), fminf(fminf(w4, w5), fminf(w6, w7)));
+          mx = fmaxf(fmaxf(fmaxf(w0, w1), fmaxf(w2, w3)), fmaxf(fmaxf(w4, w5), fmaxf(w6, w7)));
+          cc = fadd(fadd(fadd(fadd(fadd(fadd(fadd(fadd(0.f, w0), w1), w2), w3), w4), w5), w6), w7);   // vertex order
+          v0 = w0; v1 = w1; v2 = w2; v3 = w3;
+        };
+        row(0, mnx, mxx, ccx, v[0][0], v[1][0], v[2][0], v[3][0]);
+        row(1, mny, mxy, ccy, v[0][1], v[1][1], v[2][1], v[3][1]);
+        row(2, mnz, mxz, ccz, v[0][2], v[1][2], v[2][2], v[3][2]);
+      } else {
 #pragma unroll
-      for (int vtx = 0; vtx < 4; ++vtx) world_vertex(vtx, v[vtx][0], v[vtx][1], v[vtx][2]);
+        for (int vtx = 0; vtx < 4; ++vtx) world_vertex(vtx, v[vtx][0], v[vtx][1], v[vtx][2]);
 #pragma unroll 1
-      for (int vtx = 4; vtx < 8; ++vtx) {
-        float wx, wy, wz;
-        world_vertex(vtx, wx, wy, wz);
+        for (int vtx = 4; vtx < 8; ++vtx) {
+          float wx, wy, wz;
+          world_vertex(vtx, wx, wy, wz);
+        }
       }
       float* r = rec + (size_t)q * rec_words;
       r[0] = ccx / 8.f; r[1] = ccy / 8.f; r[2] = ccz / 8.f;

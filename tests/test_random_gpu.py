@@ -23,6 +23,10 @@ def random_case(rng):
     named = {"flb": (lx1, ly, lz0), "frb": (lx1, -ly, lz0), "flt": (lx1, ly, lz1), "frt": (lx1, -ly, lz1),
              "blb": (lx0, ly, lz0), "brb": (lx0, -ly, lz0), "blt": (lx0, ly, lz1), "brt": (lx0, -ly, lz1)}
     cub = configs.cuboid_vertices(named)
+    if rng.random() < 0.3:
+        # not a body-frame box: sheared / jittered vertices take the general vertex path
+        # (the collision critic still derives its OBB from vertices 0, 1, 2, 3)
+        cub = [tuple(float(c + d) for c, d in zip(v, rng.uniform(-0.05, 0.05, 3))) for v in cub]
     stack = [configs.critic(K.CRITIC_COLLISION if rng.random() < 0.8 else K.CRITIC_COLLISION_MIN_MAX)]
     if rng.random() < 0.2:
         stack.append(configs.critic(K.CRITIC_COLLISION_MIN_MAX))
