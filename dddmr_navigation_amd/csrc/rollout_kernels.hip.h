@@ -733,6 +733,7 @@ __host__ __device__ inline size_t score_lds_bytes(int tile, int max_steps, int m
   b = (b + 15) & ~(size_t)15;
   b += 16 * (size_t)(m > 0 ? m : 1);                 // plan
   b += 4 * (size_t)tile * S1;                        // dist
+  b += 16 * Q;                                       // pose positions (float) of every pair
   b += 4 * (size_t)rec_words * Q;                    // OBB records
   b += 4 * (size_t)tab_entries;                      // costmap row-run index (cell_start slice), 0 = not staged
   b = (b + 15) & ~(size_t)15;
@@ -807,6 +808,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   ofs = (ofs + 15) & ~(size_t)15;
   float4* plan = reinterpret_cast<float4*>(lds_raw + ofs);
   ofs += 16 * (size_t)(k.m > 0 ? k.m : 1);
+  float4* ppos = reinterpret_cast<float4*>(lds_raw + ofs);   // pose position of pair q (phase D1 -> P)
+  ofs += 16 * (size_t)Qcap;
   float* dist = reinterpret_cast<float*>(lds_raw + ofs);
   ofs += 4 * (size_t)tile * S1;
   float* rec = reinterpret_cast<float*>(lds_raw + ofs);
@@ -903,6 +906,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     }
     pose_translation(k, bxy, T);
     const float px = (float)T[0], py = (float)T[1], pz = (float)T[2];   // trajectory.cpp:69-75
+    ppos[q] = make_float4(px, py, pz, 0.f);
 
     // ---- cuboid -> OBB record (collision_model.cpp:85-115) ----
     if (do_coll) {
@@ -1257,10 +1261,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       if (valid) {
         while (j + 1 < nt && head[j + 1].pad <= q2) ++j;    // (dead trajectories have empty ranges)
         s = q2 - head[j].pad;
-        const float2 bxy = st_xy[(size_t)head[j].li * k.max_steps + s];
-        double T[3];
-        pose_translation(k, bxy, T);
-        px = (float)T[0]; py = (float)T[1]; pz = (float)T[2];
+        const float4 pp = ppos[head[j].pair_base + s];    // the pose D1 composed for this pair
+        px = pp.x; py = pp.y; pz = pp.z;
       }
       // exact 1-NN distance to the prune plan (FLANN float distance)
       float best = 3.402823466e+38f;
@@ -1367,8 +1369,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   }
   // wave-0 shuffle min-reduction of the packed keys, one atomic per workgroup
   if (tid < 64) {
+    static_assert(kMaxTile <= 16, "only lanes 0..kMaxTile-1 hold keys");
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
+    for (int o = 8; o > 0; o >>= 1) {
       const int64_t other = __shfl_xor(key, o, 64);
       key = other < key ? other : key;
     }
