@@ -190,7 +190,7 @@ struct dddmr_rollout_ctx {
   PerceptionScratch feed{};
 
   // pinned host memory
-  float4* cloud_stage = nullptr;
+  float4* cloud_stage[2] = {nullptr, nullptr};   // pinned staging, one per device cloud buffer
   float* small_stage = nullptr;  // axes / sample list / plan / scan upload
   DevResult* result_host = nullptr;
 
@@ -356,7 +356,8 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   for (void* p : dev)
     if (p) (void)hipFree(p);
   perception_free(ctx->feed);
-  if (ctx->cloud_stage) (void)hipHostFree(ctx->cloud_stage);
+  for (int i = 0; i < 2; ++i)
+    if (ctx->cloud_stage[i]) (void)hipHostFree(ctx->cloud_stage[i]);
   if (ctx->small_stage) (void)hipHostFree(ctx->small_stage);
   if (ctx->result_host) (void)hipHostFree(ctx->result_host);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -446,7 +447,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMalloc(&ctx->tickets, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(ctx->tickets, 0, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->poses_dev, (size_t)cfg->max_steps * 7 * sizeof(double)));
-    HIPCHK(ctx, hipHostMalloc(&ctx->cloud_stage, P * sizeof(float4), hipHostMallocDefault));
+    for (int i = 0; i < 2; ++i) HIPCHK(ctx, hipHostMalloc(&ctx->cloud_stage[i], P * sizeof(float4), hipHostMallocDefault));
     const size_t small = std::max<size_t>({3 * kMaxAxis * sizeof(float), N * sizeof(float4),
                                            plan_cap * sizeof(float4)});
     HIPCHK(ctx, hipHostMalloc(&ctx->small_stage, small, hipHostMallocDefault));
@@ -496,20 +497,30 @@ int dddmr_rollout_set_cloud(dddmr_rollout_ctx* ctx, const float* xyzi, size_t n_
     return fail(ctx, DDDMR_ERR_CAPACITY, "set_cloud: %zu points > max_points %u", n_points, ctx->cfg.max_points);
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const int back = acquire_back(ctx);
-  // repack to float4 (PCL PointXYZI is 32 bytes wide) in pinned memory
+  // The staging buffer of this slot may still feed the copy of the call before last.
+  HIPCHK(ctx, hipEventSynchronize(ctx->cloud_ready[back]));
+  // Repack to float4 (PCL PointXYZI is 32 bytes wide) in pinned memory, in a few chunks so
+  // that the DMA of one chunk runs while the next is repacked.  The call does not wait for
+  // the copies: consumers wait on cloud_ready[back] (the tick's stream does so on the device).
   const size_t sf = stride_bytes / 4;
   const bool has_i = stride_bytes >= 16;
-  for (size_t i = 0; i < n_points; ++i) {
-    const float* p = xyzi + i * sf;
-    ctx->cloud_stage[i] = make_float4(p[0], p[1], p[2], has_i ? p[3] : 0.f);
-  }
-  if (n_points) {
-    HIPCHK(ctx, hipMemcpyAsync(ctx->cloud_dev[back], ctx->cloud_stage, n_points * sizeof(float4),
-                               hipMemcpyHostToDevice, ctx->copy_stream));
+  float4* stage = ctx->cloud_stage[back];
+  const size_t kChunks = n_points >= 32768 ? 4 : 1;
+  for (size_t c = 0; c < kChunks; ++c) {
+    const size_t b = n_points * c / kChunks, e = n_points * (c + 1) / kChunks;
+    if (stride_bytes == 16) {
+      std::memcpy(stage + b, xyzi + 4 * b, (e - b) * sizeof(float4));
+    } else {
+      for (size_t i = b; i < e; ++i) {
+        const float* p = xyzi + i * sf;
+        stage[i] = make_float4(p[0], p[1], p[2], has_i ? p[3] : 0.f);
+      }
+    }
+    if (e > b)
+      HIPCHK(ctx, hipMemcpyAsync(ctx->cloud_dev[back] + b, stage + b, (e - b) * sizeof(float4), hipMemcpyHostToDevice,
+                                 ctx->copy_stream));
   }
   HIPCHK(ctx, hipEventRecord(ctx->cloud_ready[back], ctx->copy_stream));
-  // the pinned staging buffer is reused by the next call
-  HIPCHK(ctx, hipStreamSynchronize(ctx->copy_stream));
   publish_cloud(ctx, back, (uint32_t)n_points);
   return DDDMR_OK;
 }
@@ -559,6 +570,7 @@ int dddmr_rollout_get_cloud(dddmr_rollout_ctx* ctx, float* xyzi_out, size_t capa
   *n_points = n;
   if (!xyzi_out) return DDDMR_OK;
   if (capacity < n) return fail(ctx, DDDMR_ERR_CAPACITY, "get_cloud: capacity %zu < %u", capacity, n);
+  HIPCHK(ctx, hipEventSynchronize(ctx->cloud_ready[idx]));      // set_cloud returns before its copy has landed
   if (n) HIPCHK(ctx, hipMemcpy(xyzi_out, ctx->cloud_dev[idx], (size_t)n * sizeof(float4), hipMemcpyDeviceToHost));
   return DDDMR_OK;
 }
