@@ -38,9 +38,10 @@ struct FeedResult {          // host-mapped: written by the last k_feed_emit wor
 };
 
 struct PerceptionScratch {
-  float* scan_dev = nullptr;           // raw scan records (stride_floats apart)
+  float* stage_dev = nullptr;          // device address of `stage` (raw scan records, stride_floats apart)
+  uint32_t* claimed = nullptr;         // table slots claimed by this scan's voxels
   unsigned char* table = nullptr;      // [keys 8B | sums 3x8B | counts 4B] x slots, one memset clears it
-  uint32_t* counters = nullptr;        // [0] n_out, [1] ticket
+  uint32_t* counters = nullptr;        // [0] n_out, [1] ticket, [2] claimed slots
   FeedResult* res_host = nullptr;      // pinned + mapped
   FeedResult* res_dev = nullptr;
   float* stage = nullptr;              // pinned staging for the raw scan
@@ -62,7 +63,8 @@ __device__ __forceinline__ uint32_t hash_key(unsigned long long k) {
 __global__ __launch_bounds__(256) void k_feed_insert(FeedParams f, const float* __restrict__ scan, int stride_floats,
                                                      unsigned long long* __restrict__ keys,
                                                      double* __restrict__ sums, uint32_t* __restrict__ counts,
-                                                     uint32_t slot_mask) {
+                                                     uint32_t slot_mask, uint32_t* __restrict__ claimed,
+                                                     uint32_t* __restrict__ counters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= f.n) return;
   const float* sp = scan + (size_t)i * stride_floats;
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(256) void k_feed_insert(FeedParams f, const float* 
   for (uint32_t probe = 0; probe <= slot_mask; ++probe) {
     const unsigned long long prev = atomicCAS(&keys[slot], 0ull, key);
     if (prev == 0ull || prev == key) {
+      if (prev == 0ull) claimed[atomicAdd(&counters[2], 1u)] = slot;   // first point of a voxel: list its slot for the emit pass
       atomicAdd(&sums[3 * (size_t)slot + 0], (double)x);
       atomicAdd(&sums[3 * (size_t)slot + 1], (double)y);
       atomicAdd(&sums[3 * (size_t)slot + 2], (double)z);
@@ -96,11 +99,13 @@ __global__ __launch_bounds__(256) void k_feed_insert(FeedParams f, const float* 
 
 __global__ __launch_bounds__(256) void k_feed_emit(FeedParams f, unsigned long long* __restrict__ keys,
                                                    double* __restrict__ sums,
-                                                   uint32_t* __restrict__ counts, uint32_t n_slots,
+                                                   uint32_t* __restrict__ counts, const uint32_t* __restrict__ claimed,
                                                    float4* __restrict__ out, uint32_t* __restrict__ counters,
                                                    FeedResult* __restrict__ res, uint32_t seq) {
-  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool occ = slot < n_slots && keys[slot] != 0ull;
+  // one lane per occupied voxel (the slots k_feed_insert listed), not per table slot
+  const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool occ = idx < counters[2];
+  const uint32_t slot = occ ? claimed[idx] : 0u;
   // wave-aggregated append: one atomic per wave
   const unsigned long long mask = __ballot(occ);
   const int lane = threadIdx.x & 63;
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(256) void k_feed_emit(FeedParams f, unsigned long l
       res->n_out = __hip_atomic_load(&counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       counters[0] = 0;         // next call
       counters[1] = 0;
+      counters[2] = 0;
       __threadfence_system();
       __hip_atomic_store(&res->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -149,21 +155,24 @@ inline int perception_alloc(PerceptionScratch& s, size_t max_points) {
   size_t slots = 1024;
   while (slots < 2 * max_points) slots <<= 1;
   s.cap_slots = slots;
-  if (hipMalloc(&s.scan_dev, max_points * 4 * sizeof(float)) != hipSuccess) return -1;
+  if (hipMalloc(&s.claimed, max_points * sizeof(uint32_t)) != hipSuccess) return -1;
   if (hipMalloc(&s.table, feed_table_bytes(slots)) != hipSuccess) return -1;
-  if (hipMalloc(&s.counters, 2 * sizeof(uint32_t)) != hipSuccess) return -1;
+  if (hipMalloc(&s.counters, 4 * sizeof(uint32_t)) != hipSuccess) return -1;
   if (hipMemset(s.table, 0, feed_table_bytes(slots)) != hipSuccess) return -1;   // k_feed_emit keeps it clean afterwards
-  if (hipMemset(s.counters, 0, 2 * sizeof(uint32_t)) != hipSuccess) return -1;
+  if (hipMemset(s.counters, 0, 4 * sizeof(uint32_t)) != hipSuccess) return -1;
   if (hipHostMalloc(&s.res_host, sizeof(FeedResult), hipHostMallocMapped) != hipSuccess) return -1;
   if (hipHostGetDevicePointer(reinterpret_cast<void**>(&s.res_dev), s.res_host, 0) != hipSuccess) return -1;
-  if (hipHostMalloc(&s.stage, max_points * 4 * sizeof(float), hipHostMallocDefault) != hipSuccess) return -1;
+  // the raw scan is read by k_feed_insert straight from this pinned, device-mapped buffer
+  // (no separate H2D copy: the kernel's coalesced reads stream it over PCIe)
+  if (hipHostMalloc(&s.stage, max_points * 4 * sizeof(float), hipHostMallocMapped) != hipSuccess) return -1;
+  if (hipHostGetDevicePointer(reinterpret_cast<void**>(&s.stage_dev), s.stage, 0) != hipSuccess) return -1;
   s.res_host->n_out = 0;
   s.res_host->seq = 0;
   return 0;
 }
 
 inline void perception_free(PerceptionScratch& s) {
-  if (s.scan_dev) (void)hipFree(s.scan_dev);
+  if (s.claimed) (void)hipFree(s.claimed);
   if (s.table) (void)hipFree(s.table);
   if (s.counters) (void)hipFree(s.counters);
   if (s.res_host) (void)hipHostFree(s.res_host);
@@ -194,16 +203,15 @@ inline int perception_feed(PerceptionScratch& s, FeedParams f, const float* scan
       s.stage[3 * i + 2] = scan[i * sf + 2];
     }
   }
-  if (hipMemcpyAsync(s.scan_dev, s.stage, (size_t)f.n * stride_floats * sizeof(float), hipMemcpyHostToDevice, stream) != hipSuccess) return -3;
   // fixed layout over the full-capacity table; a call only uses its first `slots` entries
   unsigned long long* keys = reinterpret_cast<unsigned long long*>(s.table);
   double* sums = reinterpret_cast<double*>(s.table + s.cap_slots * 8);
   uint32_t* counts = reinterpret_cast<uint32_t*>(s.table + s.cap_slots * 32);
   const uint32_t seq = ++s.seq ? s.seq : ++s.seq;
-  hipLaunchKernelGGL(k_feed_insert, dim3((f.n + 255) / 256), dim3(256), 0, stream, f, s.scan_dev, stride_floats, keys,
-                     sums, counts, (uint32_t)(slots - 1));
-  hipLaunchKernelGGL(k_feed_emit, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, stream, f, keys, sums, counts,
-                     (uint32_t)slots, out_dev, s.counters, s.res_dev, seq);
+  hipLaunchKernelGGL(k_feed_insert, dim3((f.n + 255) / 256), dim3(256), 0, stream, f, s.stage_dev, stride_floats, keys,
+                     sums, counts, (uint32_t)(slots - 1), s.claimed, s.counters);
+  hipLaunchKernelGGL(k_feed_emit, dim3((unsigned)((f.n + 255) / 256)), dim3(256), 0, stream, f, keys, sums, counts,
+                     s.claimed, out_dev, s.counters, s.res_dev, seq);
   if (hipGetLastError() != hipSuccess) return -5;
   // poll the host-mapped sequence number (bounded), then make sure the stream is idle
   volatile uint32_t* seq_p = &s.res_host->seq;
