@@ -15,6 +15,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -184,6 +185,10 @@ struct dddmr_rollout_ctx {
   uint32_t* assign = nullptr;
   int load_theory = -1, load_nlocal = -1;   // what traj_load describes
   bool no_assign = false;
+  // DDDMR_HOST_PROF=1: host-side time of the tick's stages, printed at destroy
+  bool host_prof = false;
+  double prof_ns[4] = {0, 0, 0, 0};
+  uint64_t prof_n = 0;
   bool gnz_one = false;
   double* poses_dev = nullptr;
   // perception feed scratch
@@ -343,6 +348,10 @@ const char* dddmr_rollout_last_error(dddmr_rollout_ctx* ctx) {
 
 void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->host_prof && ctx->prof_n)
+    std::fprintf(stderr, "[dddmr] host time per tick over %llu ticks: prepare %.2f us, launches %.2f us, wait for result %.2f us\n",
+                 (unsigned long long)ctx->prof_n, ctx->prof_ns[0] / ctx->prof_n * 1e-3, ctx->prof_ns[1] / ctx->prof_n * 1e-3,
+                 ctx->prof_ns[2] / ctx->prof_n * 1e-3);
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
@@ -443,6 +452,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMemset(ctx->traj_load, 0, N * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->assign, N * sizeof(uint32_t)));
     ctx->no_assign = std::getenv("DDDMR_NO_ASSIGN") != nullptr;
+    ctx->host_prof = std::getenv("DDDMR_HOST_PROF") != nullptr;
     ctx->gnz_one = std::getenv("DDDMR_GNZ_ONE") != nullptr;
     HIPCHK(ctx, hipMalloc(&ctx->tickets, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(ctx->tickets, 0, 2 * sizeof(uint32_t)));
@@ -685,6 +695,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   out->best_index = -1;
   out->best_cost = -1.0;
   out->key = kKeyNone;
+  const auto prof_t0 = std::chrono::steady_clock::now();
   const dddmr_theory_config* th = find_theory(ctx, theory_name);
   if (!th) return fail(ctx, DDDMR_ERR_UNKNOWN_THEORY, "unknown theory '%s'", theory_name);
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -915,6 +926,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   }
   if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
 
+  const auto prof_t1 = std::chrono::steady_clock::now();
   k.seq = ++ctx->seq;
   if (k.seq == 0) k.seq = ctx->seq = 1;
   // HIP events serialise the queue around them (~3 us each); timed ticks are sampled
@@ -972,6 +984,12 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs1, ctx->stream));
   if (timed_all) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(ctx, hipGetLastError());
+  if (ctx->host_prof) {
+    const auto prof_t2 = std::chrono::steady_clock::now();
+    ctx->prof_ns[0] += std::chrono::duration<double, std::nano>(prof_t1 - prof_t0).count();
+    ctx->prof_ns[1] += std::chrono::duration<double, std::nano>(prof_t2 - prof_t1).count();
+    ++ctx->prof_n;
+  }
   unbusy.armed = false;   // the cloud buffer stays pinned until tick_collect
   ctx->pend.active = true;
   ctx->pend.k = k;
@@ -989,6 +1007,7 @@ int tick_collect(dddmr_rollout_ctx* ctx, dddmr_rollout_result* out) {
   struct Release { dddmr_rollout_ctx* c; ~Release() { release_cloud(c); } } release{ctx};
   const DevTick& k = ctx->pend.k;
   *out = ctx->pend.head;
+  const auto prof_c0 = std::chrono::steady_clock::now();
   // The last k_score workgroup stores the result into host-mapped memory and then
   // the tick's sequence number (system-scope release): polling it beats a stream
   // synchronise by several microseconds.  Bounded; falls back to the stream sync.
@@ -1011,6 +1030,7 @@ int tick_collect(dddmr_rollout_ctx* ctx, dddmr_rollout_result* out) {
   }
   const float ms = ctx->last_device_ms, score_ms = ctx->last_score_ms;   // latest sampled values
 
+  if (ctx->host_prof) ctx->prof_ns[2] += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - prof_c0).count();
   const DevResult r = *ctx->result_host;
   ctx->last_result = r;
   ctx->last = k;
