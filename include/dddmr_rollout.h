@@ -157,7 +157,10 @@ typedef struct {
   int32_t world_size;
   uint32_t max_points;       /* capacity of the aggregate observation cloud (< 2^20) */
   uint32_t max_trajectories; /* capacity of one tick's sample list (global N, < 2^24) */
-  uint32_t max_steps;        /* capacity of one trajectory's horizon (<= 4096) */
+  uint32_t max_steps;        /* capacity of one trajectory's horizon (<= 4096).  A tick whose longest
+                                trajectory does not fit one workgroup's LDS (about 700 poses with the
+                                collision critic; the shipped configs need <= 252) fails with
+                                DDDMR_ERR_CAPACITY instead of truncating */
   uint32_t max_plan_poses;   /* capacity of the prune plan (<= 512) */
   int32_t n_theories;
   int32_t reserved;
