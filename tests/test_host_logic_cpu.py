@@ -2,6 +2,7 @@
 expectations from local_planner.cpp:374-445, including the duplicated nearest pose."""
 import numpy as np
 
+from dddmr_navigation_amd import host_logic
 from dddmr_navigation_amd.host_logic import prune_plan, is_goal_reached
 
 
@@ -45,3 +46,25 @@ def test_goal_reached_is_strict_3d():
     assert is_goal_reached(plan, (0.9, 0.0, 0.29), 0.3)
     assert not is_goal_reached(plan, (0.9, 0.0, 0.3), 0.3)
     assert not is_goal_reached(plan[:0], (0, 0, 0), 0.3)
+
+
+def test_prune_plan_cloud_tags_and_order():
+    """pcl_prune_plan_ (local_planner.cpp:402-430): backward walk first, in walk order and
+    tagged -1; forward walk tagged 1 (0 only for global-plan index 0); the nearest pose
+    twice; not reversed, unlike prune_plan_.poses."""
+    g = np.zeros((30, 7)); g[:, 0] = np.arange(30) * 0.2; g[:, 6] = 1.0
+    pc = host_logic.prune_plan_cloud(g, (2.03, 0.0, 0.0), 1.0, 0.5)
+    pr = host_logic.prune_plan(g, (2.03, 0.0, 0.0), 1.0, 0.5)
+    assert pc.dtype == np.float32 and pc.shape == (len(pr), 4)
+    back = pc[pc[:, 3] < 0]
+    fwd = pc[pc[:, 3] >= 0]
+    np.testing.assert_allclose(back[:, 0], [2.0, 1.8, 1.6, 1.4], atol=1e-6)       # walk order: idx, idx-1, ...
+    np.testing.assert_allclose(fwd[:, 0], np.arange(10, 17) * 0.2, atol=1e-6)
+    assert (fwd[:, 3] == 1.0).all()
+    np.testing.assert_allclose(pr[:, 0], np.concatenate([back[::-1, 0], fwd[:, 0]]), atol=1e-6)
+    # robot at the very start of the plan: the forward walk begins at index 0 -> tag 0
+    pc0 = host_logic.prune_plan_cloud(g, (0.01, 0.0, 0.0), 1.0, 0.5)
+    assert pc0[0, 3] == -1.0 and pc0[1, 3] == 0.0 and (pc0[2:, 3] == 1.0).all()
+    # early returns mirror prune_plan
+    assert host_logic.prune_plan_cloud(g[:2], (0, 0, 0), 1.0, 0.5) is None
+    assert host_logic.prune_plan_cloud(g, (2.0, 5.0, 0.0), 1.0, 0.5) is None
