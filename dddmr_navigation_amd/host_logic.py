@@ -100,3 +100,85 @@ def is_goal_reached(global_plan: np.ndarray, robot_xyz, xy_goal_tolerance: float
         return False
     d = np.asarray(robot_xyz, dtype=np.float64) - plan[-1, :3]
     return bool(xy_goal_tolerance > math.sqrt(float(d @ d)))
+
+
+# ---- heading predicates (they produce ModelSharedData::heading_deviation_, an input of the tick) ----
+
+def _quat_to_matrix(q):
+    """tf2::Matrix3x3::setRotation(q), q = (x, y, z, w)."""
+    x, y, z, w = (float(v) for v in q)
+    d = x * x + y * y + z * z + w * w
+    s = 2.0 / d
+    xs, ys, zs = x * s, y * s, z * s
+    wx, wy, wz = w * xs, w * ys, w * zs
+    xx, xy, xz = x * xs, x * ys, x * zs
+    yy, yz, zz = y * ys, y * zs, z * zs
+    return np.array([[1.0 - (yy + zz), xy - wz, xz + wy],
+                     [xy + wz, 1.0 - (xx + zz), yz - wx],
+                     [xz - wy, yz + wx, 1.0 - (xx + yy)]])
+
+
+def _normalize_angle(a: float) -> float:
+    """angles::normalize_angle"""
+    r = math.fmod(a + math.pi, 2.0 * math.pi)
+    return r + math.pi if r <= 0.0 else r - math.pi
+
+
+def shortest_angle_from_pose_to_robot_heading(robot_pose, pose) -> float:
+    """Local_Planner::getShortestAngleFromPose2RobotHeading (local_planner.cpp:198-216):
+    yaw (tf2 getRPY, solution 1) of inverse(T_gbl_base) * pose, through
+    angles::shortest_angular_distance(0, yaw).  Poses are x y z qx qy qz qw."""
+    rb = _quat_to_matrix(robot_pose[3:7])
+    rp = _quat_to_matrix(pose[3:7])
+    m = rb.T @ rp                                   # rotation of inverse(base) * pose
+    if abs(m[2, 0]) >= 1.0:
+        yaw = 0.0                                   # getEulerYPR's gimbal-lock branch
+    else:
+        pitch = -math.asin(m[2, 0])
+        yaw = math.atan2(m[1, 0] / math.cos(pitch), m[0, 0] / math.cos(pitch))
+    return _normalize_angle(yaw - 0.0)
+
+
+def is_goal_heading_aligned(global_plan: np.ndarray, robot_pose, yaw_goal_tolerance: float):
+    """Local_Planner::isGoalHeadingAligned (local_planner.cpp:271-304) ->
+    (aligned, heading_deviation); (False, None) for an empty plan (heading_deviation_ untouched)."""
+    plan = np.asarray(global_plan, dtype=np.float64).reshape(-1, 7)
+    if len(plan) == 0:
+        return False, None
+    yaw = shortest_angle_from_pose_to_robot_heading(robot_pose, plan[-1])
+    return abs(yaw) < yaw_goal_tolerance, yaw
+
+
+def is_initial_heading_aligned(global_plan: np.ndarray, robot_pose, heading_tracking_distance: float,
+                               heading_align_angle: float):
+    """Local_Planner::isInitialHeadingAligned (local_planner.cpp:218-269) ->
+    (aligned, heading_deviation).  prunePlan(heading_tracking_distance, 0.0); fewer than 3
+    prune poses -> (False, None).  The pointing pose sits at the first prune pose and looks at
+    the last one: a planar yaw when the two are level (vz == 0, :247-252), otherwise the
+    rotation about axis x up by -acos(axis . up) with up = +x (:234-245; `right_vector.normalized()`
+    discards its result there, the quaternion constructor normalises the axis anyway)."""
+    plan = np.ascontiguousarray(global_plan, dtype=np.float64).reshape(-1, 7)
+    pr = prune_plan(plan, robot_pose[:3], heading_tracking_distance, 0.0)
+    if pr is None:
+        # prunePlan returned early and left prune_plan_ as it was; with no earlier plan that is empty
+        return False, None
+    if len(pr) < 3:
+        return False, None
+    first, last = pr[0], pr[-1]
+    vx, vy, vz = (float(v) for v in (last[:3] - first[:3]))
+    if vz != 0:
+        unit = math.sqrt(vx * vx + vy * vy + vz * vz)
+        axis = np.array([vx / unit, vy / unit, vz / unit])
+        up = np.array([1.0, 0.0, 0.0])
+        right = np.cross(axis, up)
+        angle = -1.0 * math.acos(float(axis @ up))
+        d = math.sqrt(float(right @ right))          # tf2::Quaternion(axis, angle): setRotation
+        s = math.sin(angle * 0.5) / d
+        q = np.array([right[0] * s, right[1] * s, right[2] * s, math.cos(angle * 0.5)])
+        q = q / math.sqrt(float(q @ q))              # q_pre.normalize()
+    else:
+        yaw = math.atan2(vy, vx)                     # setRPY(0, 0, yaw)
+        q = np.array([0.0, 0.0, math.sin(yaw * 0.5), math.cos(yaw * 0.5)])
+    pose = np.concatenate([first[:3], q])
+    yaw = shortest_angle_from_pose_to_robot_heading(robot_pose, pose)
+    return abs(yaw) < heading_align_angle, yaw

@@ -1,5 +1,7 @@
 """Host logic that stays on the CPU (prunePlan, goal predicate): hand-derived
 expectations from local_planner.cpp:374-445, including the duplicated nearest pose."""
+import math
+
 import numpy as np
 
 from dddmr_navigation_amd import host_logic
@@ -68,3 +70,49 @@ def test_prune_plan_cloud_tags_and_order():
     # early returns mirror prune_plan
     assert host_logic.prune_plan_cloud(g[:2], (0, 0, 0), 1.0, 0.5) is None
     assert host_logic.prune_plan_cloud(g, (2.0, 5.0, 0.0), 1.0, 0.5) is None
+
+
+def _q(yaw, pitch=0.0, roll=0.0):
+    from scipy.spatial.transform import Rotation as R
+    return tuple(R.from_euler("ZYX", [yaw, pitch, roll]).as_quat())
+
+
+def test_heading_predicates():
+    """getShortestAngleFromPose2RobotHeading / isGoalHeadingAligned / isInitialHeadingAligned
+    (local_planner.cpp:198-304) against hand-derived angles and an independent scipy rotation."""
+    from scipy.spatial.transform import Rotation as R
+    robot = (1.0, 2.0, 0.0) + _q(0.3)
+    goal = (5.0, 5.0, 0.0) + _q(1.0)
+    assert abs(host_logic.shortest_angle_from_pose_to_robot_heading(robot, goal) - 0.7) < 1e-12
+    # wrap-around: robot at +3.0 rad, pose at -3.0 rad -> +0.2832 (not -6.0)
+    y = host_logic.shortest_angle_from_pose_to_robot_heading((0, 0, 0) + _q(3.0), (0, 0, 0) + _q(-3.0))
+    assert abs(y - (2 * math.pi - 6.0)) < 1e-12
+    # tilted robot: yaw of R_b^T R_p by scipy
+    rb, rp = R.from_euler("ZYX", [0.4, 0.1, -0.05]), R.from_euler("ZYX", [-1.2, 0.02, 0.03])
+    want = (rb.inv() * rp).as_euler("ZYX")[0]
+    got = host_logic.shortest_angle_from_pose_to_robot_heading((0, 0, 0) + tuple(rb.as_quat()), (1, 1, 0) + tuple(rp.as_quat()))
+    assert abs(got - want) < 1e-12
+
+    g = straight(40, 0.1)
+    g[:, 3:7] = _q(0.0)
+    aligned, dev = host_logic.is_goal_heading_aligned(g, (0.5, 0, 0) + _q(0.2), yaw_goal_tolerance=0.25)
+    assert aligned and abs(dev + 0.2) < 1e-12
+    assert host_logic.is_goal_heading_aligned(g, (0.5, 0, 0) + _q(0.3), 0.25)[0] is False
+    assert host_logic.is_goal_heading_aligned(np.zeros((0, 7)), robot, 0.25) == (False, None)
+
+    # level plan along +x: the pointing pose has yaw 0 -> deviation = -robot yaw
+    aligned, dev = host_logic.is_initial_heading_aligned(g, (0.52, 0.01, 0.0) + _q(0.5), 1.0, 0.3)
+    assert not aligned and abs(dev + 0.5) < 1e-12
+    assert host_logic.is_initial_heading_aligned(g, (0.52, 0.01, 0.0) + _q(0.1), 1.0, 0.3)[0]
+    # plan heading 90 degrees left of the robot
+    gy = straight(40, 0.1)[:, [1, 0, 2, 3, 4, 5, 6]]
+    aligned, dev = host_logic.is_initial_heading_aligned(gy, (0.0, 0.5, 0.0) + _q(0.0), 1.0, 0.3)
+    assert abs(dev - math.pi / 2) < 1e-12
+    # sloped plan (vz != 0): axis-angle branch; the pointing pose's x axis is the plan direction
+    gs = straight(40, 0.1)
+    gs[:, 2] = 0.2 * gs[:, 0]
+    aligned, dev = host_logic.is_initial_heading_aligned(gs, (0.5, 0.0, 0.1) + _q(0.25), 1.0, 0.3)
+    assert aligned and abs(dev + 0.25) < 1e-9
+    # too short a prune plan / off the plan
+    assert host_logic.is_initial_heading_aligned(g[:2], robot, 1.0, 0.3) == (False, None)
+    assert host_logic.is_initial_heading_aligned(g, (0.5, 3.0, 0.0) + _q(0.0), 1.0, 0.3) == (False, None)
