@@ -185,6 +185,9 @@ struct dddmr_rollout_ctx {
   uint32_t* assign = nullptr;
   int load_theory = -1, load_nlocal = -1;   // what traj_load describes
   bool no_assign = false;
+  // DDDMR_POISON=1 (tests): fill the per-trajectory outputs with NaN / -1 patterns before every
+  // tick, so a trajectory the scorer skipped cannot pass for scored with last tick's values
+  bool poison = false;
   // DDDMR_HOST_PROF=1: host-side time of the tick's stages, printed at destroy
   bool host_prof = false;
   double prof_ns[4] = {0, 0, 0, 0};
@@ -452,6 +455,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMemset(ctx->traj_load, 0, N * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->assign, N * sizeof(uint32_t)));
     ctx->no_assign = std::getenv("DDDMR_NO_ASSIGN") != nullptr;
+    ctx->poison = std::getenv("DDDMR_POISON") != nullptr;
     ctx->host_prof = std::getenv("DDDMR_HOST_PROF") != nullptr;
     ctx->gnz_one = std::getenv("DDDMR_GNZ_ONE") != nullptr;
     HIPCHK(ctx, hipMalloc(&ctx->tickets, 2 * sizeof(uint32_t)));
@@ -927,6 +931,11 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
 
   const auto prof_t1 = std::chrono::steady_clock::now();
+  if (ctx->poison && k.n_local > 0) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->costs, 0xFF, (size_t)k.n_local * sizeof(double), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->steps, 0xFF, (size_t)k.n_local * sizeof(int32_t), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->samples_out, 0xFF, (size_t)k.n_local * sizeof(float4), ctx->stream));
+  }
   k.seq = ++ctx->seq;
   if (k.seq == 0) k.seq = ctx->seq = 1;
   // HIP events serialise the queue around them (~3 us each); timed ticks are sampled
