@@ -923,9 +923,13 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
       ctx->st_cap = cap;
       if (!ctx->traj_info) HIPCHK(ctx, hipMalloc(&ctx->traj_info, (size_t)ctx->cfg.max_trajectories * sizeof(TrajInfo)));
     }
-    // rollout workgroups ride along with k_bin_count (1024 lanes, one resident per CU)
-    int rt = std::min(std::max((k.n_local + ctx->n_cu - 1) / ctx->n_cu, 4), 64);
+    // Rollout workgroups ride along with k_bin_count.  Few, fat workgroups win: dispatching a
+    // 1024-lane workgroup costs ~12 ns, which is what bounds the launch on big shards (C4:
+    // 64 trajectories per workgroup 44 us, 32: 56 us, 16: 86 us), and on small ones ~128
+    // workgroups are the sweet spot (C2: 16 per workgroup 14.4 us, 32: 12.1 us, 64: 13.2 us).
+    int rt = std::min(std::max((k.n_local + 127) / 128, 4), 64);
     while (rt > 1 && rollout_lds_bytes(rt, s_tick) > (size_t)128 * 1024) --rt;
+    if (const char* e = std::getenv("DDDMR_RT")) rt = std::min(std::max(std::atoi(e), 1), 64);   // experiment
     k.rt = rt;
   }
   if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
