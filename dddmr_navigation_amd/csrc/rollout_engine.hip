@@ -946,8 +946,12 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   const bool timed = ctx->timing >= 1 && (ctx->seq % (uint32_t)ctx->timing_every) == 0;
   const bool timed_all = timed && ctx->timing >= 2;
   if (timed_all) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  const int bin_blocks = std::max(1, std::min(2048, (k.n_points + 255) / 256));
-  const int cnt_blocks = std::max(1, std::min(512, (k.n_points + kBinThreads - 1) / kBinThreads));
+  int bin_blocks = std::max(1, std::min(2048, (k.n_points + 255) / 256));
+  // one point per lane while that needs few workgroups (latency), kBinPer per lane beyond (dispatch cost)
+  const int per_wg = k.n_points <= 128 * kBinThreads ? kBinThreads : kBinThreads * kBinPer;
+  int cnt_blocks = std::max(1, std::min(512, (k.n_points + per_wg - 1) / per_wg));
+  if (const char* e = std::getenv("DDDMR_SCATTER_DIV")) bin_blocks = std::max(1, bin_blocks / std::max(1, std::atoi(e)));
+  if (const char* e = std::getenv("DDDMR_COUNT_DIV")) cnt_blocks = std::max(1, cnt_blocks / std::max(1, std::atoi(e)));
   const int roll_blocks = k.n_local > 0 ? (k.n_local + k.rt - 1) / k.rt : 0;
   const size_t roll_lds = k.n_local > 0 ? rollout_lds_bytes(k.rt, s_tick) : 0;
   k.bin_blocks = cnt_blocks;

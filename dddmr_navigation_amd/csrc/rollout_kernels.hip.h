@@ -40,6 +40,7 @@ namespace dddmr {
 // kScoreThreads): 512 lanes halve the collision walk of the heaviest tile and win when
 // the shard fits one round of resident workgroups (C2); 256 lanes keep more, smaller
 // workgroups in flight and win on big batches (C3, C4).
+constexpr int kBinPer = 4;            // points per lane and pass of a binning workgroup
 constexpr int kBinThreads = 1024;     // k_bin_count workgroup (its last workgroup scans 4096 cells per step)
 constexpr int kMaxTile = 16;          // trajectories per workgroup (upper bound)
 constexpr int kMaxPlan = 512;         // prune-plan poses kept in LDS
@@ -619,7 +620,7 @@ __global__ __launch_bounds__(256) void k_rollout(DevTick k, const float* __restr
 // and the body-frame rollout:
 // a cloud of ~10^4 points keeps only ~10 binning workgroups busy, the rollout fills
 // the rest of the chip for free and needs no cross-stream dependency.
-__global__ __launch_bounds__(kBinThreads) void k_bin_count(DevTick k, const float4* __restrict__ cloud,
+__global__ __launch_bounds__(kBinThreads, 8) void k_bin_count(DevTick k, const float4* __restrict__ cloud,
                                                    uint32_t* __restrict__ cell_count,
                                                    uint32_t* __restrict__ cell_start,
                                                    uint2* __restrict__ pt_slot, uint32_t* __restrict__ ticket,
@@ -643,17 +644,34 @@ __global__ __launch_bounds__(kBinThreads) void k_bin_count(DevTick k, const floa
   __shared__ uint32_t is_last;
   const int stride = k.bin_blocks * blockDim.x;
   DDDMR_RSTAMP(0);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k.n_points; i += stride) {
-    const float4 p = cloud[i];
-    uint2 slot = make_uint2(0xFFFFFFFFu, 0u);
-    const bool in = p.x >= k.rmin[0] && p.x <= k.rmax[0] && p.y >= k.rmin[1] && p.y <= k.rmax[1] &&
-                    p.z >= k.rmin[2] && p.z <= k.rmax[2];
-    if (in) {
-      const int c = cell_of(k, p.x, p.y, p.z);
-      slot.x = (uint32_t)c;
-      slot.y = atomicAdd(&cell_count[c], 1u);
+  // Every lane bins up to kBinPer points per pass, all their loads and counting atomics in
+  // flight together: a quarter of the workgroups (dispatching a 1024-lane workgroup costs
+  // ~12 ns, and the launch also carries the rollout's) at the latency of one point.
+  for (int base = blockIdx.x * blockDim.x + threadIdx.x; base < k.n_points; base += stride * kBinPer) {
+    float4 p[kBinPer];
+    uint2 slot[kBinPer];
+#pragma unroll
+    for (int m = 0; m < kBinPer; ++m) {
+      const int i = base + m * stride;
+      p[m] = i < k.n_points ? cloud[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    pt_slot[i] = slot;
+#pragma unroll
+    for (int m = 0; m < kBinPer; ++m) {
+      const int i = base + m * stride;
+      slot[m] = make_uint2(0xFFFFFFFFu, 0u);
+      const bool in = i < k.n_points && p[m].x >= k.rmin[0] && p[m].x <= k.rmax[0] && p[m].y >= k.rmin[1] &&
+                      p[m].y <= k.rmax[1] && p[m].z >= k.rmin[2] && p[m].z <= k.rmax[2];
+      if (in) {
+        const int c = cell_of(k, p[m].x, p[m].y, p[m].z);
+        slot[m].x = (uint32_t)c;
+        slot[m].y = atomicAdd(&cell_count[c], 1u);
+      }
+    }
+#pragma unroll
+    for (int m = 0; m < kBinPer; ++m) {
+      const int i = base + m * stride;
+      if (i < k.n_points) pt_slot[i] = slot[m];
+    }
   }
   // Ticket.  The only data handed to the last workgroup are the cell counters, and
   // those are touched exclusively by device-scope atomics (returned => performed)
