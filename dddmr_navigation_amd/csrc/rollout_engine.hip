@@ -857,20 +857,23 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     const long te = (long)(k.gnx + 1) * k.gny;
     k.tab_entries = (te <= kTabCap && k.n_points >= 5 && (k.want_collision || k.want_minmax)) ? (int)te : 0;
   }
-  // Trajectories per workgroup.  ~160 pairs per 256-thread workgroup keep the serial
-  // phases short; but when the whole shard fits ONE round of resident workgroups
-  // (4 per CU at <= 40 KB of LDS) a larger tile that reaches exactly that is faster
-  // than spilling into a second, mostly idle round (measured: 1 round ~56 us for
-  // <= 1024 workgroups, +~20 us for the next 1024).
-  // Workgroup shape.  Default: 256 lanes, ~160 pairs per workgroup (short serial
-  // phases, many small workgroups in flight: best on big batches).  When the whole
-  // shard fits ONE round of resident 512-lane workgroups (2 per CU at 4 waves per
-  // SIMD and <= 80 KB of LDS), that shape wins: the launch is bound by its heaviest
-  // tile's collision walk and 512 lanes both halve it and average over more
-  // trajectories (measured C2: 59 us vs 67 us; C3/C4 prefer 256).
+  // Workgroup shape.  Default: 256 lanes and the largest tile whose (trajectory, step)
+  // slots fit the lanes (one pair per lane in D1/D2) AND whose LDS still lets three
+  // workgroups share a CU -- measured on the big batches: C4 (50 steps) tile 3 / 4 / 5 / 6
+  // -> 420 / 342 / 364 / 519 us, C3 (81-step rows) tile 2 / 3 / 4 -> 158 / 143 / 174 us.
+  // When the whole shard fits ONE round of resident 512-lane workgroups (2 per CU at 4 waves
+  // per SIMD and <= 80 KB of LDS), that shape wins instead: the launch is bound by its
+  // heaviest tile's collision walk and 512 lanes both halve it and average over more
+  // trajectories (C2).
   int thr = 256;
-  int tile = (160 + s_tick / 2) / s_tick;
-  tile = std::min(std::max(tile, 1), kMaxTile);
+  auto tile_for_256 = [&]() {
+    int t_best = 1;
+    for (int t = 2; t <= kMaxTile; ++t)
+      if (t * s_tick <= 256 && score_lds_bytes(t, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) <= (size_t)(160 * 1024) / 3)
+        t_best = t;
+    return t_best;
+  };
+  int tile = tile_for_256();
   if (ctx->tile_override > 0) {
     tile = std::min(ctx->tile_override, kMaxTile);
     thr = ctx->threads_override > 0 ? ctx->threads_override : 256;
@@ -883,7 +886,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
       thr = 512;
       tile = std::max(fit, 1);
     }
-    if (ctx->threads_override == 256) { thr = 256; tile = std::min(std::max((160 + s_tick / 2) / s_tick, 1), kMaxTile); }
+    if (ctx->threads_override == 256) { thr = 256; tile = tile_for_256(); }
   }
   while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) > (size_t)(160 * 1024) / 2) --tile;
   const size_t lds = score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap);
