@@ -185,6 +185,7 @@ struct dddmr_rollout_ctx {
   uint32_t* assign = nullptr;
   int load_theory = -1, load_nlocal = -1;   // what traj_load describes
   bool no_assign = false;
+  bool no_boxfast = false;   // DDDMR_NO_BOXFAST: always take the general vertex transform
   // DDDMR_POISON=1 (tests): fill the per-trajectory outputs with NaN / -1 patterns before every
   // tick, so a trajectory the scorer skipped cannot pass for scored with last tick's values
   bool poison = false;
@@ -455,6 +456,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMemset(ctx->traj_load, 0, N * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->assign, N * sizeof(uint32_t)));
     ctx->no_assign = std::getenv("DDDMR_NO_ASSIGN") != nullptr;
+    ctx->no_boxfast = std::getenv("DDDMR_NO_BOXFAST") != nullptr;
     ctx->poison = std::getenv("DDDMR_POISON") != nullptr;
     ctx->host_prof = std::getenv("DDDMR_HOST_PROF") != nullptr;
     ctx->gnz_one = std::getenv("DDDMR_GNZ_ONE") != nullptr;
@@ -840,7 +842,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     bool box = true;
     for (int v = 0; v < 8; ++v)
       for (int a = 0; a < 3; ++a) box = box && (c[v][a] == want[v][a]);
-    k.box_fast = (box && !std::getenv("DDDMR_NO_BOXFAST")) ? 1 : 0;
+    k.box_fast = (box && !ctx->no_boxfast) ? 1 : 0;
   }
 
   // trajectories per workgroup: ~one (trajectory, step) pair per lane
@@ -932,7 +934,6 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     // workgroups are the sweet spot (C2: 16 per workgroup 14.4 us, 32: 12.1 us, 64: 13.2 us).
     int rt = std::min(std::max((k.n_local + 127) / 128, 4), 64);
     while (rt > 1 && rollout_lds_bytes(rt, s_tick) > (size_t)128 * 1024) --rt;
-    if (const char* e = std::getenv("DDDMR_RT")) rt = std::min(std::max(std::atoi(e), 1), 64);   // experiment
     k.rt = rt;
   }
   if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
@@ -949,12 +950,10 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   const bool timed = ctx->timing >= 1 && (ctx->seq % (uint32_t)ctx->timing_every) == 0;
   const bool timed_all = timed && ctx->timing >= 2;
   if (timed_all) HIPCHK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  int bin_blocks = std::max(1, std::min(2048, (k.n_points + 255) / 256));
+  const int bin_blocks = std::max(1, std::min(2048, (k.n_points + 255) / 256));
   // one point per lane while that needs few workgroups (latency), kBinPer per lane beyond (dispatch cost)
   const int per_wg = k.n_points <= 128 * kBinThreads ? kBinThreads : kBinThreads * kBinPer;
-  int cnt_blocks = std::max(1, std::min(512, (k.n_points + per_wg - 1) / per_wg));
-  if (const char* e = std::getenv("DDDMR_SCATTER_DIV")) bin_blocks = std::max(1, bin_blocks / std::max(1, std::atoi(e)));
-  if (const char* e = std::getenv("DDDMR_COUNT_DIV")) cnt_blocks = std::max(1, cnt_blocks / std::max(1, std::atoi(e)));
+  const int cnt_blocks = std::max(1, std::min(512, (k.n_points + per_wg - 1) / per_wg));
   const int roll_blocks = k.n_local > 0 ? (k.n_local + k.rt - 1) / k.rt : 0;
   const size_t roll_lds = k.n_local > 0 ? rollout_lds_bytes(k.rt, s_tick) : 0;
   k.bin_blocks = cnt_blocks;
