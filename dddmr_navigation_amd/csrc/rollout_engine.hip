@@ -859,20 +859,28 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     const long te = (long)(k.gnx + 1) * k.gny;
     k.tab_entries = (te <= kTabCap && k.n_points >= 5 && (k.want_collision || k.want_minmax)) ? (int)te : 0;
   }
-  // Workgroup shape.  Default: 256 lanes and the largest tile whose (trajectory, step)
-  // slots fit the lanes (one pair per lane in D1/D2) AND whose LDS still lets three
-  // workgroups share a CU -- measured on the big batches: C4 (50 steps) tile 3 / 4 / 5 / 6
-  // -> 420 / 342 / 364 / 519 us, C3 (81-step rows) tile 2 / 3 / 4 -> 158 / 143 / 174 us.
+  // Workgroup shape.  Default: 256 lanes and the tile that keeps the most (trajectory, step)
+  // slots resident per CU with the slots of one workgroup fitting its lanes (one pair per
+  // lane in D1/D2) -- measured on the big batches: C4 (50 steps) tile 3 / 4 / 5 / 6
+  // -> 420 / 342 / 364 / 519 us (39 KB of LDS at tile 4: four workgroups per CU, 47 KB at
+  // tile 5: three), C3 (80-step rows) tile 2 / 3 / 4 -> 158 / 143 / 174 us.
   // When the whole shard fits ONE round of resident 512-lane workgroups (2 per CU at 4 waves
   // per SIMD and <= 80 KB of LDS), that shape wins instead: the launch is bound by its
   // heaviest tile's collision walk and 512 lanes both halve it and average over more
   // trajectories (C2).
   int thr = 256;
   auto tile_for_256 = [&]() {
+    // most (trajectory, step) slots resident per CU: workgroups per CU (4 by registers, fewer
+    // by LDS) x slots per workgroup, slots <= lanes
     int t_best = 1;
-    for (int t = 2; t <= kMaxTile; ++t)
-      if (t * s_tick <= 256 && score_lds_bytes(t, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) <= (size_t)(160 * 1024) / 3)
-        t_best = t;
+    long best = 0;
+    for (int t = 1; t <= kMaxTile; ++t) {
+      if (t > 1 && t * s_tick > 256) break;
+      const size_t need = score_lds_bytes(t, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) + 1024;   // + static LDS
+      const long wgs = std::min<long>(4, (long)((size_t)(160 * 1024) / need));
+      const long resident = wgs * t * s_tick;
+      if (resident >= best) { best = resident; t_best = t; }
+    }
     return t_best;
   };
   int tile = tile_for_256();
@@ -893,6 +901,9 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) > (size_t)(160 * 1024) / 2) --tile;
   const size_t lds = score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap);
   if (lds > (size_t)kScoreLdsMax) return fail(ctx, DDDMR_ERR_CAPACITY, "horizon needs %zu bytes of LDS", lds);
+  if (ctx->seq == 3 && std::getenv("DDDMR_DEBUG_GRID"))
+    std::fprintf(stderr, "[dddmr] k_score shape: %d lanes, tile %d, %d-step rows, %zu bytes of dynamic LDS (tile+1 would need %zu)\n", thr, tile, s_tick, lds,
+                 score_lds_bytes(tile + 1, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap));
   k.tile = tile;
 
 
