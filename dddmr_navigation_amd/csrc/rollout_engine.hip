@@ -222,6 +222,7 @@ struct dddmr_rollout_ctx {
   bool have_last = false;
   Window last_window;
   float cell_size = 0.25f;
+  bool cell_forced = false;   // DDDMR_CELL given: no automatic growth on big shards
   int tile_override = 0;
   int threads_override = 0;   // DDDMR_THREADS: force the 256- or 512-lane k_score
   int n_cu = 256;   // compute units of the device
@@ -411,7 +412,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
   ctx->device = cfg->device;
   if (const char* e = std::getenv("DDDMR_CELL")) {
     const float v = (float)std::atof(e);
-    if (v > 0.01f && v < 10.f) ctx->cell_size = v;
+    if (v > 0.01f && v < 10.f) { ctx->cell_size = v; ctx->cell_forced = true; }
   }
   if (const char* e = std::getenv("DDDMR_TILE")) ctx->tile_override = std::atoi(e);
   if (const char* e = std::getenv("DDDMR_THREADS")) ctx->threads_override = std::atoi(e) == 512 ? 512 : 256;
@@ -818,6 +819,14 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
       diam = std::max(diam, std::sqrt(dx * dx + dy * dy + dz * dz));
     }
   float cell = std::max(ctx->cell_size, (float)(std::min(diam, 2.0) * 1.001 / (kRows - 2)));
+  // Big shards run many 256-lane workgroups per CU and are bound by how many (trajectory,
+  // step) slots fit a CU's LDS; a slot's row segments are the largest part of it, so there the
+  // cells grow until a cuboid spans at most 4 rows (C3 k_score 143 -> 122 us, C4 342 -> 298 us
+  // at 0.42 m).  Shards that fit one round of 512-lane workgroups keep the small cells: their
+  // LDS is not the limit and bigger cells make the counting atomics collide (C2 binning
+  // +3 us at 0.42 m, +7 us at 0.5 m).
+  if (!ctx->cell_forced && k.n_local > ctx->n_cu * kMaxTile)
+    cell = std::max(cell, std::min(0.5f, (float)(std::min(diam, 2.0) * 1.001 / 2.9)));
   for (;;) {
     k.gnx = std::max(1, (int)std::ceil((k.rmax[0] - k.rmin[0]) / cell));
     k.gny = std::max(1, (int)std::ceil((k.rmax[1] - k.rmin[1]) / cell));
