@@ -819,6 +819,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
       diam = std::max(diam, std::sqrt(dx * dx + dy * dy + dz * dz));
     }
   float cell = std::max(ctx->cell_size, (float)(std::min(diam, 2.0) * 1.001 / (kRows - 2)));
+  float cell_z = cell;     // z cells do not grow with the x/y cells below
   // Big shards run many 256-lane workgroups per CU and are bound by how many (trajectory,
   // step) slots fit a CU's LDS; a slot's row segments are the largest part of it, so there the
   // cells grow until a cuboid spans at most 4 rows (C3 k_score 143 -> 122 us, C4 342 -> 298 us
@@ -832,12 +833,14 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     k.gny = std::max(1, (int)std::ceil((k.rmax[1] - k.rmin[1]) / cell));
     // Candidate runs always take every z of a row, but one cell column per (x, y) makes the
     // counting atomics of wall points collide (measured: k_bin_count 13 -> 17 us); keep z.
-    k.gnz = ctx->gnz_one ? 1 : std::max(1, (int)std::ceil((k.rmax[2] - k.rmin[2]) / cell));
+    k.gnz = ctx->gnz_one ? 1 : std::max(1, (int)std::ceil((k.rmax[2] - k.rmin[2]) / cell_z));
     const uint64_t nc = (uint64_t)k.gnx * k.gny * k.gnz;
     if (nc <= kCapCells && k.gnx < 32000 && k.gny < 32000) { k.n_cells = (int)nc; break; }
     cell *= 1.5f;
+    cell_z *= 1.5f;
   }
   k.inv_cell = 1.0f / cell;
+  k.inv_cell_z = 1.0f / cell_z;
   for (int i = 0; i < 3; ++i) k.gmin[i] = k.rmin[i];
   // rows <= floor(span / cell) + 2 (span = cuboid diameter clipped to the 2 m search ball)
   k.rows_cap = std::min(kRows, (int)std::floor(std::min(diam, 2.0) * 1.001 / cell) + 2);

@@ -85,6 +85,7 @@ struct DevTick {
   int n_cells;
   float gmin[3];
   float inv_cell;
+  float inv_cell_z;  // z cells keep the small size when x/y cells grow: they only spread the counting atomics
   float rmin[3], rmax[3];   // region accepted by the binning pass
   int tile;          // trajectories per workgroup
   int want_collision, want_minmax;
@@ -233,7 +234,7 @@ __device__ __forceinline__ void sincos_quarter_ahead(const double ang, const dou
 __device__ __forceinline__ int cell_of(const DevTick& k, float x, float y, float z) {
   int cx = (int)floorf((x - k.gmin[0]) * k.inv_cell);
   int cy = (int)floorf((y - k.gmin[1]) * k.inv_cell);
-  int cz = (int)floorf((z - k.gmin[2]) * k.inv_cell);
+  int cz = (int)floorf((z - k.gmin[2]) * k.inv_cell_z);
   cx = min(max(cx, 0), k.gnx - 1);
   cy = min(max(cy, 0), k.gny - 1);
   cz = min(max(cz, 0), k.gnz - 1);
