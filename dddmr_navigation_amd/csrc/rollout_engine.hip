@@ -474,8 +474,10 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     if (rc != 0) return fail(ctx, DDDMR_ERR_HIP, "perception scratch allocation failed");
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_bin_count), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<256>), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
-    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<512>), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<256, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<512, true>), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<512, false>), hipFuncAttributeMaxDynamicSharedMemorySize, kScoreLdsMax));
     HIPCHK(ctx, hipDeviceSynchronize());
     return DDDMR_OK;
   };
@@ -1010,16 +1012,15 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
   if (k.n_local > 0) {
     const int wgs = k.n_tiles;
-    if (thr == 512)
-      hipLaunchKernelGGL(k_score<512>, dim3(wgs), dim3(512), lds, ctx->stream, k, ctx->traj_info,
-                         ctx->st_sc, ctx->st_xy, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
-                         ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev,
-                         ctx->assign, ctx->traj_load);
-    else
-      hipLaunchKernelGGL(k_score<256>, dim3(wgs), dim3(256), lds, ctx->stream, k, ctx->traj_info,
-                         ctx->st_sc, ctx->st_xy, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,
-                         ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev,
-                         ctx->assign, ctx->traj_load);
+    const bool lean = !k.want_minmax && !k.rec_pose;
+#define DDDMR_LAUNCH_SCORE(T, L)                                                                                   \
+  hipLaunchKernelGGL((k_score<T, L>), dim3(wgs), dim3(T), lds, ctx->stream, k, ctx->traj_info, ctx->st_sc,        \
+                     ctx->st_xy, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,             \
+                     ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev, ctx->assign, \
+                     ctx->traj_load)
+    if (thr == 512) { if (lean) DDDMR_LAUNCH_SCORE(512, true); else DDDMR_LAUNCH_SCORE(512, false); }
+    else            { if (lean) DDDMR_LAUNCH_SCORE(256, true); else DDDMR_LAUNCH_SCORE(256, false); }
+#undef DDDMR_LAUNCH_SCORE
   } else {
     hipLaunchKernelGGL(k_empty_result, dim3(1), dim3(64), 0, ctx->stream, k, ctx->cell_start, ctx->result_dev);
   }

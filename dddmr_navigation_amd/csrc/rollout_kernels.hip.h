@@ -806,7 +806,10 @@ __device__ __forceinline__ void pose_translation(const DevTick& k, float2 bxy, d
   for (int i = 0; i < 3; ++i) T[i] = k.R[3 * i + 0] * (double)bxy.x + k.R[3 * i + 1] * (double)bxy.y + k.t[i];
 }
 
-template <int kScoreThreads>
+// kLean: the common critic stack -- no min-max critic and no pair that needs the 1 m radius test
+// (the cuboid lies inside the search ball) -- as compile-time facts: the walk loses its radius /
+// min-max code and the records their optional words.
+template <int kScoreThreads, bool kLean>
 __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     DevTick k, const TrajInfo* __restrict__ info, const double2* __restrict__ st_sc, const float2* __restrict__ st_xy,
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
@@ -818,9 +821,10 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   const int tile = k.tile;
   const int S1 = k.max_steps + 1;
   const int Qcap = tile * k.max_steps;
-  const bool need_box = k.want_collision != 0, need_mm = k.want_minmax != 0;
-  const int rec_words = rec_words_of(k.rec_pose != 0, need_mm);
-  const int mm_ofs = kRecBase + (k.rec_pose ? 3 : 0);
+  const bool need_box = k.want_collision != 0, need_mm = !kLean && k.want_minmax != 0;
+  const bool rec_pose = !kLean && k.rec_pose != 0;
+  const int rec_words = rec_words_of(rec_pose, need_mm);
+  const int mm_ofs = kRecBase + (rec_pose ? 3 : 0);
   size_t ofs = 0;
   TrajHead* head = reinterpret_cast<TrajHead*>(lds_raw);
   ofs += sizeof(TrajHead) * (size_t)tile;
@@ -944,12 +948,12 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         mny = fminf(mny, wy); mxy = fmaxf(mxy, wy);
         mnz = fminf(mnz, wz); mxz = fmaxf(mxz, wz);
         ccx = fadd(ccx, wx); ccy = fadd(ccy, wy); ccz = fadd(ccz, wz);   // centre sum in vertex order
-        if (k.rec_pose) {
+        if (rec_pose) {
           const float ux = wx - px, uy = wy - py, uz = wz - pz;
           vmax2 = fmaxf(vmax2, ux * ux + uy * uy + uz * uz);
         }
       };
-      if (k.box_fast && !k.rec_pose) {
+      if (k.box_fast && !rec_pose) {
         // The cuboid is a box in the body frame (x back/front, y left/right, z bottom/top --
         // checked bit for bit on the host), so the 24 products L(i,c) * coordinate take only
         // 18 distinct values and the partial sums L(i,0) x + L(i,1) y only 12: same
@@ -1011,8 +1015,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       reinterpret_cast<int*>(r)[16] = (cy0 & 0xFFFF) | (cy1 << 16);
       // A point inside the (convex) box is no farther from the pose than the farthest
       // vertex, so with all vertices well inside the 1 m ball the radius test is moot.
-      reinterpret_cast<int*>(r)[17] = j | ((vmax2 < 0.99f || !k.rec_pose) ? 0x10000 : 0);
-      if (k.rec_pose) { r[18] = px; r[19] = py; r[20] = pz; }
+      reinterpret_cast<int*>(r)[17] = j | ((vmax2 < 0.99f || !rec_pose) ? 0x10000 : 0);
+      if (rec_pose) { r[18] = px; r[19] = py; r[20] = pz; }
       if (need_mm) {
         float* rm = r + mm_ofs;
         rm[0] = mnx; rm[1] = mny; rm[2] = mnz; rm[3] = mxx; rm[4] = mxy; rm[5] = mxz;
