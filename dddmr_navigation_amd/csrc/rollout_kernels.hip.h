@@ -1168,8 +1168,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       const uint32_t n = min((uint32_t)kItem, (sl_len >> 12) - off);
       // kItem independent loads in flight (the sorted array is padded by kItem)
       Pt3 pt[kItem];
-  #pragma unroll
-      for (int u = 0; u < kItem; ++u) pt[u] = sorted[p0 + u];
+      const Pt3* __restrict__ src = sorted + p0;     // one 64-bit address, the 16 loads use immediate offsets
+#pragma unroll
+      for (int u = 0; u < kItem; ++u) pt[u] = src[u];
       float r[18];
   #pragma unroll
       for (int u = 0; u < 15; ++u) r[u] = rq[u];
