@@ -1182,9 +1182,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   #pragma unroll
         for (int u = 0; u < kItem; u += 2) {
           const int h2 = box_test2(r, pt[u], pt[u + 1], use_radius);
-          hits |= ((uint32_t)u < n ? (h2 & 1) : 0) | ((uint32_t)(u + 1) < n ? (h2 & 2) : 0);
+          hits |= h2 << u;                             // one bit per point ...
         }
-        fb = hits != 0;
+        fb = (hits & ((1 << n) - 1)) != 0;             // ... and the padding of a partial item masked once
       }
       if (need_mm) {
   #pragma unroll
