@@ -88,3 +88,26 @@ def test_edge_cases_and_ratio_arithmetic():
         lp.set_cloud(sc.cloud[:60])
         lp.setPlan(sc.plan)
         assert lp.tick(th.name.decode(), sc.tick).n_samples > 0
+
+
+def test_state_guards_of_the_query_entry_points():
+    """path_blocked / pose arrays refuse to run while a tick_begin is pending, and pose arrays
+    need a finished tick; errors leave the context usable."""
+    sc = scenes.bench_scene("C1")
+    name = sc.theory.name.decode()
+    pc = np.array([[0.5, 0, 0, 1]], np.float32)
+    with LocalPlanner([sc.theory]) as lp:
+        lp.set_cloud(sc.cloud)
+        lp.setPlan(sc.plan)
+        with pytest.raises(RolloutError) as e:
+            lp.pose_arrays()
+        assert e.value.code == K.ERR_STATE
+        lp.tick_begin(name, sc.tick)
+        for call in (lambda: lp.path_blocked(pc, 0.3), lambda: lp.pose_arrays(), lambda: lp.best_poses()):
+            with pytest.raises(RolloutError) as e:
+                call()
+            assert e.value.code == K.ERR_STATE
+        res = lp.tick_end()
+        assert res.n_samples > 0
+        assert len(lp.pose_arrays()) == int(lp.debug()[1].clip(min=0).sum())
+        assert lp.path_blocked(pc, 0.3)[1] in (K.OPINION_PASS, K.OPINION_PATH_BLOCKED_WAIT)
