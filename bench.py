@@ -60,14 +60,25 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-            # fail early (and loudly) if RCCL cannot move 8 bytes between the ranks
-            probe = torch.full((1,), rank, dtype=torch.int64, device=dev)
-            dist.all_reduce(probe, op=dist.ReduceOp.MIN)
-            assert int(probe.item()) == 0
+        backend = args.backend
+        if backend == "nccl":
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                # fail early if RCCL cannot move 8 bytes between the ranks
+                probe = torch.full((1,), rank, dtype=torch.int64, device=dev)
+                dist.all_reduce(probe, op=dist.ReduceOp.MIN)
+                assert int(probe.item()) == 0
+            except Exception as e:        # the 8-byte key reduce also works over gloo: say so and go on
+                print(f"[bench] RCCL unavailable ({type(e).__name__}: {e}); falling back to gloo", file=sys.stderr, flush=True)
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                backend = "gloo"
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        args.backend = backend
     red_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     # ---- workload ----
@@ -235,6 +246,7 @@ def main():
                        "trajectories_per_gpu": n_local, "steps_per_trajectory": n_steps_traj,
                        "trajectory_steps_per_s": round(value * n_steps_traj, 1),
                        "parallelism": f"traj-shard x{world}" if world > 1 else "single",
+                       "key_reduce": (("RCCL" if args.backend == "nccl" else args.backend) + " all_reduce(MIN), 8 bytes per tick") if world > 1 else None,
                        "cmd_vel": [res.vx, res.vy, res.wz], "best_index": int(res.best_index),
                        "cmd_vel_matches_oracle": parity_ok},
             "roofline": roofline, "cpu_baseline": cpu,
