@@ -34,6 +34,8 @@ def parse():
     ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--backend", default=os.environ.get("DDDMR_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse ranks on one GPU)")
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="independent planner contexts (robots) per GPU, one tick in flight each; 1 = sequential ticks (the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -136,7 +138,30 @@ def main():
         prev_key[0] = None
         pending.append((dist.all_reduce(buf, op=dist.ReduceOp.MIN, async_op=True), buf))
 
+    # --contexts M (single GPU): M independent contexts share the GPU, each with one tick in
+    # flight -- what a host planning for several robots does.  A step still is one full tick.
+    lps = [lp]
+    inflight = [False]
+    if args.contexts > 1:
+        if world > 1 or scans is not None:
+            raise SystemExit("--contexts needs --gpus 1 and a resident-cloud workload")
+        for _ in range(args.contexts - 1):
+            extra = LocalPlanner([theory], device=gpu, max_points=len(sc.cloud), max_trajectories=1 << 20)
+            extra.set_cloud(sc.cloud)
+            extra.setPlan(sc.plan)
+            lps.append(extra)
+            inflight.append(False)
+    last_res = [None]
+
     def step():
+        if len(lps) > 1:
+            j = step_no[0] % len(lps)
+            if inflight[j]:
+                last_res[0] = lps[j].tick_end()
+            lps[j].tick_begin(name, sc.tick)
+            inflight[j] = True
+            step_no[0] += 1
+            return last_res[0]
         if scans is not None:
             lp.set_scan(scans[step_no[0] % len(scans)], t_bs, t_gb, 10.0, 2.0)
         if world > 1:
@@ -152,6 +177,10 @@ def main():
         return res
 
     def fence():
+        for j in range(len(lps)):
+            if inflight[j]:
+                last_res[0] = lps[j].tick_end()
+                inflight[j] = False
         if world > 1:
             collect()
             issue()
@@ -167,13 +196,17 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
-        if lp.last_result.score_ms > 0:
-            score_ms.append(lp.last_result.score_ms)      # latest sampled HIP-event duration of k_score
-        dev_ms.append(lp.last_result.device_ms)
+        lr = lp.last_result
+        if lr is not None:
+            if lr.score_ms > 0:
+                score_ms.append(lr.score_ms)              # latest sampled HIP-event duration of k_score
+            dev_ms.append(lr.device_ms)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
         res = resolved[0]
+    if len(lps) > 1:
+        res = last_res[0]
     if world > 1:
         et = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
@@ -245,12 +278,15 @@ def main():
                                    + (", 16x1800 LiDAR scan -> set_scan (voxel-hash feed) fused into every step" if scans is not None else ""),
                        "trajectories_per_gpu": n_local, "steps_per_trajectory": n_steps_traj,
                        "trajectory_steps_per_s": round(value * n_steps_traj, 1),
-                       "parallelism": f"traj-shard x{world}" if world > 1 else "single",
+                       "parallelism": f"traj-shard x{world}" if world > 1 else ("single" if len(lps) == 1 else f"{len(lps)} independent contexts on one GPU, one tick in flight each"),
+                       "contexts_per_gpu": len(lps),
                        "key_reduce": (("RCCL" if args.backend == "nccl" else args.backend) + " all_reduce(MIN), 8 bytes per tick") if world > 1 else None,
                        "cmd_vel": [res.vx, res.vy, res.wz], "best_index": int(res.best_index),
                        "cmd_vel_matches_oracle": parity_ok},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+    for extra in lps[1:]:
+        extra.close()
     lp.close()
     if world > 1:
         dist.barrier()
