@@ -29,8 +29,8 @@ import numpy as np  # noqa: E402
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="C2", choices=["C2", "C3", "C4", "C5"])
     ap.add_argument("--backend", default=os.environ.get("DDDMR_BENCH_BACKEND", "nccl"),
                     help="torch.distributed backend (nccl = RCCL over xGMI; gloo only to rehearse ranks on one GPU)")
