@@ -174,6 +174,20 @@ __device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, fl
   return fadd(fadd(fmul(ax, bx), fmul(ay, by)), fmul(az, bz));
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves (register-to-register, a few
+// cycles each) instead of LDS-crossbar shuffles: Hillis-Steele inside the 16-lane rows
+// (row_shr 1, 2, 4, 8; lanes without a source add 0), then the row totals are carried over
+// with row_bcast:15 (into rows 1 and 3) and row_bcast:31 (into rows 2 and 3).
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+  return v;
+}
+
 // sin and cos of a heading in double.  The rollout's phase B is bound by exactly this
 // (one call per pose), and ocml's sincos spends most of its instructions on argument
 // ranges a heading never has.  fdlibm's algorithm for |x| < 2^20 pi/2: Cody-Waite
@@ -260,12 +274,7 @@ __device__ inline void scan_cells(const DevTick& k, uint32_t* __restrict__ cell_
       if (i0 + j < n) cell_count[i0 + j] = 0u;
     }
     const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
-    uint32_t incl = tsum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
+    const uint32_t incl = wave_incl_scan_u32(tsum);
     if (lane == 63) wave_sum[wid] = incl;
     __syncthreads();
     uint32_t wofs = 0, total = 0;
@@ -574,12 +583,7 @@ __device__ __forceinline__ void assign_block(const DevTick& k, const int grp, co
   __syncthreads();
   // exclusive scan of the classes, one per lane
   const uint32_t cnt = hist[tid];
-  uint32_t inc = cnt;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t up = __shfl_up(inc, o, 64);
-    if ((tid & 63) >= o) inc += up;
-  }
+  const uint32_t inc = wave_incl_scan_u32(cnt);
   if ((tid & 63) == 63) wsum[tid >> 6] = inc;
   __syncthreads();
   uint32_t base = inc - cnt;
@@ -1101,12 +1105,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
           }
         }
       }
-      unsigned long long incl = cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const unsigned long long up = __shfl_up(incl, o, 64);
-        if (lane >= o) incl += up;
-      }
+      // (segments in the high word, items in the low word: two 32-bit DPP scans)
+      const unsigned long long incl = ((unsigned long long)wave_incl_scan_u32((uint32_t)(cnt >> 32)) << 32) |
+                                      (unsigned long long)wave_incl_scan_u32((uint32_t)cnt);
       if (lane == 63) wsum64[wid] = incl;
       __syncthreads();
       unsigned long long wofs = 0, tot = 0;
