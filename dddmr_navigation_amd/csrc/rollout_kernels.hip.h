@@ -188,6 +188,26 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
   return v;
 }
 
+// DPP row_shl:N (lane i reads lane i+N of its 16-lane row; lanes without a source keep their own
+// value) for 32- and 64-bit payloads: the building block of reductions towards lane 0 of a group.
+template <int N>
+__device__ __forceinline__ int dpp_row_shl(int v) {
+  return __builtin_amdgcn_update_dpp(v, v, 0x100 + N, 0xF, 0xF, false);
+}
+template <int N>
+__device__ __forceinline__ float dpp_row_shl(float v) {
+  return __int_as_float(dpp_row_shl<N>(__float_as_int(v)));
+}
+template <int N>
+__device__ __forceinline__ long long dpp_row_shl(long long v) {
+  const int lo = dpp_row_shl<N>((int)(v & 0xFFFFFFFFll)), hi = dpp_row_shl<N>((int)(v >> 32));
+  return ((long long)hi << 32) | (long long)(unsigned int)lo;
+}
+template <int N>
+__device__ __forceinline__ double dpp_row_shl(double v) {
+  return __longlong_as_double(dpp_row_shl<N>(__double_as_longlong(v)));
+}
+
 // sin and cos of a heading in double.  The rollout's phase B is bound by exactly this
 // (one call per pose), and ocml's sincos spends most of its instructions on argument
 // ranges a heading never has.  fdlibm's algorithm for |x| < 2^20 pi/2: Cody-Waite
@@ -1305,7 +1325,11 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
           best = fminf(best, l2_simple(pp.x, pp.y, pp.z, px, py, pz));
         }
       }
-      for (int o = 1; o < G; o <<= 1) best = fminf(best, __shfl_xor(best, o, 64));
+      // minimum over the G (<= 16, aligned) lanes of a pose, gathered in its first lane
+      if (G > 1) best = fminf(best, dpp_row_shl<1>(best));
+      if (G > 2) best = fminf(best, dpp_row_shl<2>(best));
+      if (G > 4) best = fminf(best, dpp_row_shl<4>(best));
+      if (G > 8) best = fminf(best, dpp_row_shl<8>(best));
       if (valid && g == 0) dist[(size_t)j * S1 + s] = sqrtf(best);
     }
   }
@@ -1313,16 +1337,20 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   DDDMR_STAMP(8);   // end of phase P
 
   // StickPath's sum of per-step distances (stick_path_model.cpp:62-73): one wave per
-  // trajectory, lanes stride the steps, fixed xor-shuffle tree in double (the
+  // trajectory, lanes stride the steps, fixed reduction tree in double (the
   // reference adds in step order; the difference is <= 1e-15 relative).
   for (int j = wid; j < nt; j += kScoreThreads / 64) {
     const int ns = head[j].steps;
     const float* dr = dist + (size_t)j * S1;
     double acc = 0.0;
     for (int s2 = lane; s2 < ns; s2 += 64) acc += (double)dr[s2];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) head[j].stick_sum = acc;
+    // fixed tree: inside the 16-lane rows towards their first lane (DPP), then the four row sums
+    acc += dpp_row_shl<8>(acc);
+    acc += dpp_row_shl<4>(acc);
+    acc += dpp_row_shl<2>(acc);
+    acc += dpp_row_shl<1>(acc);
+    const double r1 = __shfl(acc, 16, 64), r2 = __shfl(acc, 32, 64), r3 = __shfl(acc, 48, 64);
+    if (lane == 0) head[j].stick_sum = (acc + r1) + (r2 + r3);
   }
   __syncthreads();
 
@@ -1395,10 +1423,13 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   // wave-0 shuffle min-reduction of the packed keys, one atomic per workgroup
   if (tid < 64) {
     static_assert(kMaxTile <= 16, "only lanes 0..kMaxTile-1 hold keys");
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-      const int64_t other = __shfl_xor(key, o, 64);
-      key = other < key ? other : key;
+    {
+      long long kk = (long long)key, o;
+      o = dpp_row_shl<8>(kk); kk = o < kk ? o : kk;
+      o = dpp_row_shl<4>(kk); kk = o < kk ? o : kk;
+      o = dpp_row_shl<2>(kk); kk = o < kk ? o : kk;
+      o = dpp_row_shl<1>(kk); kk = o < kk ? o : kk;
+      key = (int64_t)kk;                                   // lane 0: minimum of lanes 0..15
     }
     if (tid == 0 && key != kKeyNone) atomicMin((long long*)best_key, (long long)key);
   }
