@@ -918,13 +918,11 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   }
   __syncthreads();
   DDDMR_STAMP(1);   // end of phase A
-  // pair offsets (tile <= 16: serial prefix by one lane)
-  if (tid == 0) {
-    int acc = 0;
-    for (int j = 0; j < nt; ++j) {
-      head[j].pair_base = acc;
-      acc += head[j].steps;
-    }
+  // pair offsets
+  if (tid < 64) {                                   // exclusive prefix of the step counts: one DPP wave scan
+    const uint32_t st = tid < nt ? (uint32_t)head[tid].steps : 0u;
+    const uint32_t incl = wave_incl_scan_u32(st);
+    if (tid < nt) head[tid].pair_base = (int)(incl - st);
   }
   __syncthreads();
   DDDMR_STAMP(2);
@@ -1234,14 +1232,15 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     };
     const int n_rounds = total > (uint32_t)kScoreThreads ? 2 : 1;
     for (int round = 0; round < n_rounds; ++round) {
-      if (tid == 0) {
-        uint32_t acc = 0;
-        for (int j = 0; j < nt; ++j) {
-          t_ubase[j] = acc;
-          const bool decided = round > 0 && (!need_box || head[j].hit_box != 0) && (!need_mm || head[j].hit_mm != 0);
-          if (!decided) acc += t_item0[j + 1] - t_item0[j];
+      if (tid < 64) {                               // exclusive prefix of the undecided trajectories' item counts
+        uint32_t cnt = 0;
+        if (tid < nt) {
+          const bool decided = round > 0 && (!need_box || head[tid].hit_box != 0) && (!need_mm || head[tid].hit_mm != 0);
+          if (!decided) cnt = t_item0[tid + 1] - t_item0[tid];
         }
-        t_ubase[nt] = acc;
+        const uint32_t incl = wave_incl_scan_u32(cnt);
+        if (tid < nt) t_ubase[tid] = incl - cnt;
+        if (tid == nt - 1) t_ubase[nt] = incl;
       }
       __syncthreads();
       const uint32_t tot_r = t_ubase[nt];
@@ -1279,14 +1278,15 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   // reference never reaches them after CollisionModel returned -1
   // (stacked_scoring_model.cpp:83-86).  With most samples colliding in cluttered
   // scenes this skips most of the 1-NN searches.
-  if (tid == 0) {
-    int acc = 0;
-    for (int j = 0; j < nt; ++j) {
-      const bool dead = cloud_ok && ((need_box && head[j].hit_box) || (need_mm && head[j].hit_mm));
-      head[j].pad = acc;                                  // first surviving pair of trajectory j
-      acc += dead ? 0 : head[j].steps;
+  if (tid < 64) {
+    uint32_t st = 0;
+    if (tid < nt) {
+      const bool dead = cloud_ok && ((need_box && head[tid].hit_box) || (need_mm && head[tid].hit_mm));
+      st = dead ? 0u : (uint32_t)head[tid].steps;
     }
-    alive_pairs_s = acc;
+    const uint32_t incl = wave_incl_scan_u32(st);
+    if (tid < nt) head[tid].pad = (int)(incl - st);         // first surviving pair of trajectory tid
+    if (tid == max(nt, 1) - 1) alive_pairs_s = nt > 0 ? (int)incl : 0;
   }
   __syncthreads();
   {
