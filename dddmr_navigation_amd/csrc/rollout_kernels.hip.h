@@ -1093,6 +1093,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     // lane then writes its own segments.  Empty rows (open space: most of them) are
     // dropped so the walk never has to step over them.
     unsigned long long carry = 0;
+    if (tid <= kMaxTile) t_item0[tid] = 0u;           // per-trajectory item counts (a barrier follows inside the loop)
     for (int base = 0; base < total_pairs; base += kScoreThreads) {
       const int q = base + tid;
       uint32_t rb[kRows], rl[kRows];
@@ -1136,11 +1137,9 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         tot += v;
       }
       const unsigned long long ex = carry + wofs + incl - cnt;
-      if (q < total_pairs) {
-        const int jq = reinterpret_cast<const int*>(rec + (size_t)q * rec_words)[17] & 0xFFFF;
-        if (q == head[jq].pair_base) t_item0[jq] = (uint32_t)ex;   // items in front of the trajectory's first pair
-      }
       if (cnt) {
+        // items of this pair towards its trajectory's total (-> first item of every trajectory below)
+        atomicAdd(&t_item0[reinterpret_cast<const int*>(rec + (size_t)q * rec_words)[17] & 0xFFFF], (uint32_t)cnt);
         uint32_t ci = (uint32_t)(ex >> 32), itn = (uint32_t)ex;
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
@@ -1158,11 +1157,12 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     }
     const int nseg = (int)(carry >> 32);
     const uint32_t total = (uint32_t)carry;
-    if (tid == 0) {
-      pref[nseg] = total;
-      t_item0[nt] = total;
-      for (int j = nt - 1; j >= 0; --j)               // trajectories without poses own no items
-        if (head[j].steps == 0) t_item0[j] = t_item0[j + 1];
+    if (tid == 0) pref[nseg] = total;
+    if (tid < 64) {                                   // per-trajectory item counts -> first item (exclusive scan)
+      const uint32_t c = tid < nt ? t_item0[tid] : 0u;
+      const uint32_t incl = wave_incl_scan_u32(c);
+      if (tid < nt) t_item0[tid] = incl - c;
+      if (tid == nt - 1) t_item0[nt] = incl;          // == total
     }
     __syncthreads();
 
