@@ -29,7 +29,7 @@ with LocalPlanner([sc.theory], max_points=max(len(sc.cloud), 16)) as lp:
     used &= st[:, 7] > 0
     st = st[used]
     print(cfg, "workgroups", len(st), "score_ms", r.score_ms)
-    names = ["A theta", "B trig+index", "C xy", "D1 pose/path/obb", "D2 segments+scan", "D3 walk", "E score"]
+    names = ["A headers+index", "pair offsets", "(unused)", "D1 pose/obb", "D2 segments+scan", "D3 walk", "P+E path+score"]
     t0 = st[:, 0].min()
     for i, nm in enumerate(names):
         d = (st[:, i + 1] - st[:, i]) / 1000.0   # kilo-cycles (s_memtime counts shader clocks)
