@@ -1,3 +1,7 @@
+"""Determinism probe: set_scan -> tick, set_cloud -> tick, tick again; prints how many per-trajectory
+costs differ between the ticks (they must not: any tile assignment gives identical results) and
+against the oracle.  This is how the backend-fused copy of the 1-NN loop was found.
+usage: python tools/dbg_feed.py"""
 import numpy as np, sys
 sys.path.insert(0,'.')
 from dddmr_navigation_amd import scenes

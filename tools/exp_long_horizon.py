@@ -1,3 +1,5 @@
+"""Long horizons (rotate-in-place with a fine angular granularity): parity at ~600 steps, and the
+clean capacity error beyond what one workgroup's LDS holds.  usage: python tools/exp_long_horizon.py"""
 import numpy as np, sys
 from dddmr_navigation_amd import configs, scenes, _capi as K
 from dddmr_navigation_amd.local_planner import LocalPlanner, RolloutError
