@@ -1129,12 +1129,19 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
                                       (unsigned long long)wave_incl_scan_u32((uint32_t)cnt);
       if (lane == 63) wsum64[wid] = incl;
       __syncthreads();
-      unsigned long long wofs = 0, tot = 0;
-#pragma unroll
-      for (int wv = 0; wv < kScoreThreads / 64; ++wv) {
-        const unsigned long long v = wsum64[wv];
-        if (wv < wid) wofs += v;
-        tot += v;
+      // offsets of the waves: one LDS read per lane, a DPP scan over the <= 8 wave totals, two readlanes
+      unsigned long long wofs, tot;
+      {
+        constexpr int kW = kScoreThreads / 64;
+        const unsigned long long v = lane < kW ? wsum64[lane] : 0ull;
+        const uint32_t ihi = wave_incl_scan_u32((uint32_t)(v >> 32)), ilo = wave_incl_scan_u32((uint32_t)v);
+        const int w_u = __builtin_amdgcn_readfirstlane(wid);
+        tot = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ihi, kW - 1) << 32) |
+              (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ilo, kW - 1);
+        const int prev = w_u > 0 ? w_u - 1 : 0;
+        const unsigned long long pw = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ihi, prev) << 32) |
+                                      (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)ilo, prev);
+        wofs = w_u > 0 ? pw : 0ull;
       }
       const unsigned long long ex = carry + wofs + incl - cnt;
       if (cnt) {
