@@ -297,12 +297,12 @@ __device__ inline void scan_cells(const DevTick& k, uint32_t* __restrict__ cell_
     const uint32_t incl = wave_incl_scan_u32(tsum);
     if (lane == 63) wave_sum[wid] = incl;
     __syncthreads();
-    uint32_t wofs = 0, total = 0;
-    for (int w = 0; w < nw; ++w) {
-      const uint32_t x = wave_sum[w];
-      if (w < wid) wofs += x;
-      total += x;
-    }
+    // offsets of the <= 16 waves: one LDS read, a DPP scan, two readlanes
+    const uint32_t wincl = wave_incl_scan_u32(lane < nw ? wave_sum[lane] : 0u);
+    const int w_u = __builtin_amdgcn_readfirstlane(wid);
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)wincl, 15);      // lanes >= nw add 0
+    const uint32_t wprev = (uint32_t)__builtin_amdgcn_readlane((int)wincl, w_u > 0 ? w_u - 1 : 0);
+    const uint32_t wofs = w_u > 0 ? wprev : 0u;
     const uint32_t carry = *carry_s;
     uint32_t run = carry + wofs + incl - tsum;
 #pragma unroll
