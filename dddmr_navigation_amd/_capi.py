@@ -14,7 +14,7 @@ import os
 
 MAX_CRITICS = 8
 NAME_LEN = 64
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # dddmr_status
 OK = 0
@@ -157,12 +157,15 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_tick_begin",
     "dddmr_rollout_tick_end",
     "dddmr_rollout_resolve",
+    "dddmr_rollout_winner_words",
+    "dddmr_rollout_resolve_words",
     "dddmr_rollout_get_debug",
     "dddmr_rollout_get_best_poses",
     "dddmr_rollout_get_pose_arrays",
     "dddmr_rollout_path_blocked",
     "dddmr_rollout_pack_key",
     "dddmr_rollout_key_index",
+    "dddmr_rollout_stream_ceiling",
     "dddmr_rollout_last_error",
     "dddmr_rollout_version",
 )
@@ -212,6 +215,10 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_tick_end.restype = C.c_int
     lib.dddmr_rollout_resolve.argtypes = [ctx_p, C.c_int64, C.POINTER(RolloutResult)]
     lib.dddmr_rollout_resolve.restype = C.c_int
+    lib.dddmr_rollout_winner_words.argtypes = [C.POINTER(RolloutResult), C.POINTER(C.c_int64)]
+    lib.dddmr_rollout_winner_words.restype = None
+    lib.dddmr_rollout_resolve_words.argtypes = [ctx_p, C.POINTER(C.c_int64), C.c_int32, C.POINTER(RolloutResult)]
+    lib.dddmr_rollout_resolve_words.restype = C.c_int
     lib.dddmr_rollout_get_debug.argtypes = [ctx_p, C.POINTER(RolloutDebug)]
     lib.dddmr_rollout_get_debug.restype = C.c_int
     lib.dddmr_rollout_get_best_poses.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
@@ -225,6 +232,8 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_pack_key.restype = C.c_int64
     lib.dddmr_rollout_key_index.argtypes = [C.c_int64]
     lib.dddmr_rollout_key_index.restype = C.c_int32
+    lib.dddmr_rollout_stream_ceiling.argtypes = [ctx_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.dddmr_rollout_stream_ceiling.restype = C.c_int
     lib.dddmr_rollout_last_error.argtypes = [ctx_p]
     lib.dddmr_rollout_last_error.restype = C.c_char_p
     lib.dddmr_rollout_version.argtypes = []

@@ -13,7 +13,6 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
-#include <condition_variable>
 #include <cstdarg>
 #include <chrono>
 #include <cstdio>
@@ -25,6 +24,7 @@
 
 #include "rollout_kernels.hip.h"
 #include "perception_kernels.hip.h"
+#include "measure_kernels.hip.h"
 
 using namespace dddmr;
 
@@ -33,6 +33,7 @@ namespace {
 constexpr uint32_t kCapCells = 1u << 20;
 constexpr int kMaxAxis = 4096;
 constexpr int kScoreLdsMax = 150 * 1024;   // dynamic LDS one k_score workgroup may use
+constexpr int kCloudBufs = 3;              // front / busy / free, see dddmr_rollout_ctx
 
 struct Window {              // result of a theory's initialise()
   std::vector<float> ax, ay, ath;
@@ -160,11 +161,11 @@ struct dddmr_rollout_ctx {
   double2* st_sc = nullptr;
   float2* st_xy = nullptr;
   size_t st_cap = 0;       // (trajectory, step) pairs the state arrays hold
-  hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr, cloud_ready[2] = {nullptr, nullptr};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr, cloud_ready[kCloudBufs] = {nullptr, nullptr, nullptr};
 
   // device memory
-  float4* cloud_dev[2] = {nullptr, nullptr};
-  uint32_t cloud_n[2] = {0, 0};
+  float4* cloud_dev[kCloudBufs] = {nullptr, nullptr, nullptr};
+  uint32_t cloud_n[kCloudBufs] = {0, 0, 0};
   uint2* pt_slot = nullptr;
   Pt3* sorted = nullptr;
   uint32_t *cell_count = nullptr, *cell_start = nullptr;
@@ -199,7 +200,7 @@ struct dddmr_rollout_ctx {
   PerceptionScratch feed{};
 
   // pinned host memory
-  float4* cloud_stage[2] = {nullptr, nullptr};   // pinned staging, one per device cloud buffer
+  float4* cloud_stage[kCloudBufs] = {nullptr, nullptr, nullptr};   // pinned staging, one per device cloud buffer
   float* small_stage = nullptr;  // axes / sample list / plan / scan upload
   DevResult* result_host = nullptr;
 
@@ -207,14 +208,18 @@ struct dddmr_rollout_ctx {
   uint32_t plan_m = 0;
   double plan_last[7] = {0, 0, 0, 0, 0, 0, 1};
 
-  // cloud double buffer
+  // Cloud triple buffer: `front` is the published observation the next tick reads, `busy` the one
+  // a pending tick (or path_blocked) is reading, and there is always a third that is neither, so
+  // set_cloud / set_scan never wait for a tick and never overwrite what one reads.
   std::mutex cloud_mu;
-  std::condition_variable cloud_cv;
-  int front = 0;      // buffer the next tick reads
-  int busy = -1;      // buffer a running tick is reading
-  bool front_pending = false;
+  std::mutex producer_mu;   // serialises set_cloud / set_scan callers (one producer at a time)
+  int front = 0;
+  int busy = -1;
+  // buffer i was published but no wait on cloud_ready[i] has been enqueued on `stream` yet
+  bool wait_pending[kCloudBufs] = {false, false, false};
 
   std::mutex tick_mu;
+  std::mutex err_mu;        // last_error is written by tick and sensor threads alike
   std::string last_error;
 
   // last tick (for get_debug / get_best_poses / resolve)
@@ -253,7 +258,10 @@ int fail(dddmr_rollout_ctx* ctx, int code, const char* fmt, ...) {
   va_start(ap, fmt);
   vsnprintf(buf, sizeof(buf), fmt, ap);
   va_end(ap);
-  if (ctx) ctx->last_error = buf;
+  if (ctx) {
+    std::lock_guard<std::mutex> lk(ctx->err_mu);
+    ctx->last_error = buf;
+  }
   return code;
 }
 
@@ -348,7 +356,14 @@ int64_t dddmr_rollout_pack_key(double cost, uint32_t global_index) { return pack
 int32_t dddmr_rollout_key_index(int64_t key) { return key_index(key); }
 
 const char* dddmr_rollout_last_error(dddmr_rollout_ctx* ctx) {
-  return ctx ? ctx->last_error.c_str() : "null context";
+  if (!ctx) return "null context";
+  // a per-thread copy: another thread may replace the context's string at any time
+  static thread_local std::string copy;
+  {
+    std::lock_guard<std::mutex> lk(ctx->err_mu);
+    copy = ctx->last_error;
+  }
+  return copy.c_str();
 }
 
 void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
@@ -360,7 +375,7 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < kCloudBufs; ++i) {
     if (ctx->cloud_dev[i]) (void)hipFree(ctx->cloud_dev[i]);
     if (ctx->cloud_ready[i]) (void)hipEventDestroy(ctx->cloud_ready[i]);
   }
@@ -370,7 +385,7 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   for (void* p : dev)
     if (p) (void)hipFree(p);
   perception_free(ctx->feed);
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < kCloudBufs; ++i)
     if (ctx->cloud_stage[i]) (void)hipHostFree(ctx->cloud_stage[i]);
   if (ctx->small_stage) (void)hipHostFree(ctx->small_stage);
   if (ctx->result_host) (void)hipHostFree(ctx->result_host);
@@ -435,7 +450,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipEventCreate(&ctx->evs1));
     const size_t P = cfg->max_points, N = cfg->max_trajectories;
     const size_t plan_cap = std::max<uint32_t>(cfg->max_plan_poses, 1);
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < kCloudBufs; ++i) {
       HIPCHK(ctx, hipMalloc(&ctx->cloud_dev[i], P * sizeof(float4)));
       HIPCHK(ctx, hipEventCreateWithFlags(&ctx->cloud_ready[i], hipEventDisableTiming));
     }
@@ -451,7 +466,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMalloc(&ctx->costs, N * sizeof(double)));
     HIPCHK(ctx, hipMalloc(&ctx->steps, N * sizeof(int32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->samples_out, N * sizeof(float4)));
-    HIPCHK(ctx, hipMalloc(&ctx->best_key, sizeof(int64_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->best_key, 2 * sizeof(int64_t)));
     HIPCHK(ctx, hipMalloc(&ctx->overflow, sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->traj_load, N * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(ctx->traj_load, 0, N * sizeof(uint32_t)));
@@ -464,7 +479,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMalloc(&ctx->tickets, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(ctx->tickets, 0, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->poses_dev, (size_t)cfg->max_steps * 7 * sizeof(double)));
-    for (int i = 0; i < 2; ++i) HIPCHK(ctx, hipHostMalloc(&ctx->cloud_stage[i], P * sizeof(float4), hipHostMallocDefault));
+    for (int i = 0; i < kCloudBufs; ++i) HIPCHK(ctx, hipHostMalloc(&ctx->cloud_stage[i], P * sizeof(float4), hipHostMallocDefault));
     const size_t small = std::max<size_t>({3 * kMaxAxis * sizeof(float), N * sizeof(float4),
                                            plan_cap * sizeof(float4)});
     HIPCHK(ctx, hipHostMalloc(&ctx->small_stage, small, hipHostMallocDefault));
@@ -496,15 +511,31 @@ static void publish_cloud(dddmr_rollout_ctx* ctx, int idx, uint32_t n) {
   std::lock_guard<std::mutex> lk(ctx->cloud_mu);
   ctx->cloud_n[idx] = n;
   ctx->front = idx;
-  ctx->front_pending = true;
+  ctx->wait_pending[idx] = true;
 }
 
-// Pick the back buffer; if a running tick still reads it, wait for that tick.
+// Pick the buffer to fill: neither the published front nor the one a pending tick reads.
+// Never waits (the round-1 double buffer blocked -- on one thread forever -- when a second
+// observation arrived while a tick_begin was pending); producer_mu must be held.
 static int acquire_back(dddmr_rollout_ctx* ctx) {
-  std::unique_lock<std::mutex> lk(ctx->cloud_mu);
-  const int back = 1 - ctx->front;
-  ctx->cloud_cv.wait(lk, [&] { return ctx->busy != back; });
-  return back;
+  std::lock_guard<std::mutex> lk(ctx->cloud_mu);
+  for (int i = 0; i < kCloudBufs; ++i)
+    if (i != ctx->front && i != ctx->busy) return i;
+  return -1;   // unreachable: three buffers, two exclusions
+}
+
+// Pin the front buffer for a consumer on ctx->stream (tick_mu held).  *need_wait says whether the
+// stream still has to wait for the buffer's upload; call cloud_wait_done() once that wait is enqueued.
+static int pin_front(dddmr_rollout_ctx* ctx, bool* need_wait) {
+  std::lock_guard<std::mutex> lk(ctx->cloud_mu);
+  const int idx = ctx->front;
+  ctx->busy = idx;
+  *need_wait = ctx->wait_pending[idx];
+  return idx;
+}
+static void cloud_wait_done(dddmr_rollout_ctx* ctx, int idx) {
+  std::lock_guard<std::mutex> lk(ctx->cloud_mu);
+  ctx->wait_pending[idx] = false;   // (idx is pinned, so it cannot have been republished meanwhile)
 }
 
 int dddmr_rollout_set_cloud(dddmr_rollout_ctx* ctx, const float* xyzi, size_t n_points,
@@ -515,8 +546,9 @@ int dddmr_rollout_set_cloud(dddmr_rollout_ctx* ctx, const float* xyzi, size_t n_
   if (n_points > ctx->cfg.max_points)
     return fail(ctx, DDDMR_ERR_CAPACITY, "set_cloud: %zu points > max_points %u", n_points, ctx->cfg.max_points);
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> prod(ctx->producer_mu);
   const int back = acquire_back(ctx);
-  // The staging buffer of this slot may still feed the copy of the call before last.
+  // The staging buffer of this slot may still feed the copy of an earlier call.
   HIPCHK(ctx, hipEventSynchronize(ctx->cloud_ready[back]));
   // Repack to float4 (PCL PointXYZI is 32 bytes wide) in pinned memory, in a few chunks so
   // that the DMA of one chunk runs while the next is repacked.  The call does not wait for
@@ -554,6 +586,7 @@ int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_po
   if (n_points > ctx->cfg.max_points)
     return fail(ctx, DDDMR_ERR_CAPACITY, "set_scan: %zu points > max_points %u", n_points, ctx->cfg.max_points);
   HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> prod(ctx->producer_mu);
   const int back = acquire_back(ctx);
   FeedParams fp;
   quat_to_rot(T_base_sensor, fp.Rbs);
@@ -579,13 +612,11 @@ int dddmr_rollout_get_cloud(dddmr_rollout_ctx* ctx, float* xyzi_out, size_t capa
   if (!ctx || !n_points) return DDDMR_ERR_BAD_ARG;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
-  int idx;
-  uint32_t n;
-  {
-    std::lock_guard<std::mutex> lk(ctx->cloud_mu);
-    idx = ctx->front;
-    n = ctx->cloud_n[idx];
-  }
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "get_cloud while a tick_begin is pending");
+  bool pending;
+  const int idx = pin_front(ctx, &pending);     // a producer must not recycle the buffer while it is copied
+  struct Release { dddmr_rollout_ctx* c; ~Release() { release_cloud(c); } } release{ctx};
+  const uint32_t n = ctx->cloud_n[idx];
   *n_points = n;
   if (!xyzi_out) return DDDMR_OK;
   if (capacity < n) return fail(ctx, DDDMR_ERR_CAPACITY, "get_cloud: capacity %zu < %u", capacity, n);
@@ -607,14 +638,8 @@ int dddmr_rollout_path_blocked(dddmr_rollout_ctx* ctx, const float* plan_xyzi, s
   *opinion = DDDMR_OPINION_PASS;
   if (blocked_flags) std::memset(blocked_flags, 0, n_plan);
   // pin the front cloud like a tick does
-  int cidx;
   bool pending;
-  {
-    std::lock_guard<std::mutex> lk(ctx->cloud_mu);
-    cidx = ctx->front;
-    ctx->busy = cidx;
-    pending = ctx->front_pending;       // stays set: the next tick still has to wait for the upload
-  }
+  const int cidx = pin_front(ctx, &pending);
   struct Release { dddmr_rollout_ctx* c; ~Release() { release_cloud(c); } } release{ctx};
   const uint32_t n_points = ctx->cloud_n[cidx];
   if (n_points <= 5 || n_plan == 0) return DDDMR_OK;                  // path_blocked_strategy.cpp:62-64
@@ -643,7 +668,10 @@ int dddmr_rollout_path_blocked(dddmr_rollout_ctx* ctx, const float* plan_xyzi, s
       HIPCHK(ctx, hipMalloc(&ctx->blocked_plan, kBlockedMaxPlan * sizeof(float4)));
       HIPCHK(ctx, hipMalloc(&ctx->blocked_flags, (kBlockedMaxPlan / 32) * sizeof(uint32_t)));
     }
-    if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
+    if (pending) {
+      HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
+      cloud_wait_done(ctx, cidx);
+    }
     HIPCHK(ctx, hipMemcpyAsync(ctx->blocked_plan, plan_xyzi, n_plan * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->blocked_flags, 0, (kBlockedMaxPlan / 32) * sizeof(uint32_t), ctx->stream));
     const int blocks = (int)std::min<uint32_t>(1024, (n_points + 255) / 256);
@@ -691,8 +719,8 @@ int dddmr_rollout_set_prune_plan(dddmr_rollout_ctx* ctx, const double* poses, si
 namespace {
 
 void release_cloud(dddmr_rollout_ctx* c) {
-  { std::lock_guard<std::mutex> lk(c->cloud_mu); c->busy = -1; }
-  c->cloud_cv.notify_all();
+  std::lock_guard<std::mutex> lk(c->cloud_mu);
+  c->busy = -1;
 }
 
 // Enqueue one tick (host-side initialise() + 3 launches); tick_mu must be held.
@@ -795,15 +823,10 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   k.max_steps = s_tick;
 
   // ---- cloud front buffer + local costmap tile ----
-  int cidx;
+  // (the "upload still pending" flag is only cleared once the stream wait below is enqueued: an
+  // early error return in between must not lose the ordering against copy_stream)
   bool pending;
-  {
-    std::lock_guard<std::mutex> lk(ctx->cloud_mu);
-    cidx = ctx->front;
-    ctx->busy = cidx;
-    pending = ctx->front_pending;
-    ctx->front_pending = false;
-  }
+  const int cidx = pin_front(ctx, &pending);
   struct Unbusy {          // releases the cloud buffer again if enqueueing fails half-way
     dddmr_rollout_ctx* c;
     bool armed = true;
@@ -961,7 +984,10 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     while (rt > 1 && rollout_lds_bytes(rt, s_tick) > (size_t)128 * 1024) --rt;
     k.rt = rt;
   }
-  if (pending) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
+  if (pending) {
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->cloud_ready[cidx], 0));
+    cloud_wait_done(ctx, cidx);
+  }
 
   const auto prof_t1 = std::chrono::steady_clock::now();
   if (ctx->poison && k.n_local > 0) {
@@ -1127,6 +1153,19 @@ int dddmr_rollout_tick_end(dddmr_rollout_ctx* ctx, dddmr_rollout_result* out) {
   return tick_collect(ctx, out);
 }
 
+// the command of global sample `idx` of the last collected tick (samples are a closed-form grid, or the
+// tick's explicit list: every rank can recompute the winner's command from its index)
+static void sample_of(const Window& w, int idx, float* vx, float* vy, float* wz) {
+  if (w.list_mode) {
+    *vx = w.list[idx].x; *vy = w.list[idx].y; *wz = w.list[idx].z;
+  } else {
+    const int nth = (int)w.ath.size(), ny = (int)w.ay.size();
+    *vx = w.ax[(idx / nth) / ny];
+    *vy = w.ay[(idx / nth) % ny];
+    *wz = w.ath[idx % nth];
+  }
+}
+
 int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key, dddmr_rollout_result* inout) {
   if (!ctx || !inout) return DDDMR_ERR_BAD_ARG;
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
@@ -1141,18 +1180,8 @@ int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key, dddmr_rol
     return DDDMR_OK;
   }
   if (idx >= ctx->last.n_global) return fail(ctx, DDDMR_ERR_BAD_ARG, "resolve: index %d out of range", idx);
-  // samples are a closed-form grid (or the tick's explicit list): every rank can
-  // recompute the winner's command from its index
-  const Window& w = ctx->last_window;
   float vx, vy, wz;
-  if (w.list_mode) {
-    vx = w.list[idx].x; vy = w.list[idx].y; wz = w.list[idx].z;
-  } else {
-    const int nth = (int)w.ath.size(), ny = (int)w.ay.size();
-    vx = w.ax[(idx / nth) / ny];
-    vy = w.ay[(idx / nth) % ny];
-    wz = w.ath[idx % nth];
-  }
+  sample_of(ctx->last_window, idx, &vx, &vy, &wz);
   inout->planner_state = DDDMR_TRAJECTORY_FOUND;
   inout->best_index = idx;
   inout->vx = vx; inout->vy = vy; inout->wz = wz;
@@ -1165,6 +1194,97 @@ int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key, dddmr_rol
     inout->best_cost = cv.d;
   }
   return DDDMR_OK;
+}
+
+void dddmr_rollout_winner_words(const dddmr_rollout_result* r, int64_t words[2]) {
+  words[0] = words[1] = INT64_MAX;
+  if (!r || r->best_index < 0) return;
+  words[0] = cost_bits(r->best_cost);
+  if (words[0] != INT64_MAX) words[1] = -(int64_t)r->best_index;
+}
+
+int dddmr_rollout_resolve_words(dddmr_rollout_ctx* ctx, const int64_t* words, int32_t n_ranks,
+                                dddmr_rollout_result* inout) {
+  if (!ctx || !inout || !words || n_ranks <= 0) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (!ctx->have_last) return fail(ctx, DDDMR_ERR_STATE, "resolve before any tick");
+  // minimum cost (full doubles), equal costs -> highest index: local_planner.cpp:460 over the whole batch
+  int64_t c = INT64_MAX, ni = INT64_MAX;
+  for (int r = 0; r < n_ranks; ++r) {
+    const int64_t cr = words[2 * r], ir = words[2 * r + 1];
+    if (cr == INT64_MAX) continue;
+    if (cr < c || (cr == c && ir < ni)) { c = cr; ni = ir; }
+  }
+  if (c == INT64_MAX) {
+    inout->planner_state = DDDMR_ALL_TRAJECTORIES_FAIL;
+    inout->best_index = -1;
+    inout->best_cost = -1.0;
+    inout->vx = inout->vy = inout->wz = 0.0;
+    inout->key = kKeyNone;
+    return DDDMR_OK;
+  }
+  const int64_t idx = -ni;
+  if (idx < 0 || idx >= ctx->last.n_global) return fail(ctx, DDDMR_ERR_BAD_ARG, "resolve_words: index %lld out of range", (long long)idx);
+  float vx, vy, wz;
+  sample_of(ctx->last_window, (int)idx, &vx, &vy, &wz);
+  union { double d; int64_t i; } cv;
+  cv.i = c;
+  inout->planner_state = DDDMR_TRAJECTORY_FOUND;
+  inout->best_index = (int32_t)idx;
+  inout->best_cost = cv.d;
+  inout->vx = vx; inout->vy = vy; inout->wz = wz;
+  inout->key = pack_key(cv.d, (uint32_t)idx);
+  return DDDMR_OK;
+}
+
+// Stream ceiling of this GPU ("a measured stream-copy ceiling on the same GPU ... both
+// denominators"): `bytes` per buffer (>= 1 GiB defeats the 256 MB of MALL), `reps` launches each.
+int dddmr_rollout_stream_ceiling(dddmr_rollout_ctx* ctx, size_t bytes, int32_t reps, double* copy_gbps,
+                                 double* read_gbps) {
+  if (!ctx || !copy_gbps || !read_gbps || reps <= 0 || bytes < (1u << 20)) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "stream_ceiling while a tick_begin is pending");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  const size_t n = bytes / sizeof(float4);
+  const int blocks = ctx->n_cu * 8;
+  float4 *src = nullptr, *dst = nullptr;
+  float* sink = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  int rc = DDDMR_OK;
+  auto run = [&]() -> int {
+    HIPCHK(ctx, hipMalloc(&src, n * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&dst, n * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&sink, (size_t)blocks * 256 * sizeof(float)));
+    HIPCHK(ctx, hipMemsetAsync(src, 0x11, n * sizeof(float4), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(dst, 0, n * sizeof(float4), ctx->stream));
+    HIPCHK(ctx, hipEventCreate(&e0));
+    HIPCHK(ctx, hipEventCreate(&e1));
+    float ms = 0.f;
+    hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, ctx->stream, src, dst, n);   // warm-up
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_stream_copy, dim3(blocks), dim3(256), 0, ctx->stream, src, dst, n);
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    *copy_gbps = 2.0 * (double)(n * sizeof(float4)) * reps / ((double)ms * 1e-3) / 1e9;
+    hipLaunchKernelGGL(k_stream_read, dim3(blocks), dim3(256), 0, ctx->stream, src, sink, n);
+    HIPCHK(ctx, hipEventRecord(e0, ctx->stream));
+    for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_stream_read, dim3(blocks), dim3(256), 0, ctx->stream, src, sink, n);
+    HIPCHK(ctx, hipEventRecord(e1, ctx->stream));
+    HIPCHK(ctx, hipEventSynchronize(e1));
+    HIPCHK(ctx, hipEventElapsedTime(&ms, e0, e1));
+    *read_gbps = (double)(n * sizeof(float4)) * reps / ((double)ms * 1e-3) / 1e9;
+    HIPCHK(ctx, hipGetLastError());
+    return DDDMR_OK;
+  };
+  rc = run();
+  (void)hipStreamSynchronize(ctx->stream);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (src) (void)hipFree(src);
+  if (dst) (void)hipFree(dst);
+  if (sink) (void)hipFree(sink);
+  return rc;
 }
 
 int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg) {

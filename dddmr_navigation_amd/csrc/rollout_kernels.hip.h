@@ -46,6 +46,7 @@ constexpr int kMaxTile = 16;          // trajectories per workgroup (upper bound
 constexpr int kMaxPlan = 512;         // prune-plan poses kept in LDS
 constexpr int kInlineAxes = 192;      // sample-axis floats that travel inside the kernel arguments
 constexpr int64_t kKeyNone = INT64_MAX;
+constexpr double kMaxAcceptedCost = 9999999.0;   // local_planner.cpp:452
 // a cell-sorted point: 12 bytes -- the collision walk is bound by the bytes the lanes
 // pull through the vector L1, and the intensity word is never read
 struct Pt3 { float x, y, z; };
@@ -129,11 +130,21 @@ __host__ __device__ inline int64_t pack_key(double cost, uint32_t gidx) {
   // positive doubles order like their bit patterns; keep the top 40 bits of the
   // cost and put (max - index) below so that min(key) = min cost, ties -> highest
   // index (local_planner.cpp:460-463 keeps the LAST minimal trajectory).
-  if (!(cost >= 0.0)) return kKeyNone;
+  // (getBestTrajectory starts from minimum_cost = 9999999 and accepts cost_ <= minimum_cost,
+  // local_planner.cpp:452,460: a larger cost is never accepted)
+  if (!(cost >= 0.0 && cost <= kMaxAcceptedCost)) return kKeyNone;
   union { double d; uint64_t u; } c;
   c.d = cost;
   const uint64_t idx_mask = (1ull << kKeyIndexBits) - 1;
   return (int64_t)((c.u & ~idx_mask) | (idx_mask - (uint64_t)gidx));
+}
+// The full bit pattern of an acceptable cost (non-negative doubles order like their bits):
+// reduced beside the packed key so that the winner is exact, see k_score's decode.
+__host__ __device__ inline int64_t cost_bits(double cost) {
+  if (!(cost >= 0.0 && cost <= kMaxAcceptedCost)) return kKeyNone;
+  union { double d; int64_t i; } c;
+  c.d = cost;
+  return c.i;
 }
 __host__ __device__ inline int32_t key_index(int64_t key) {
   if (key == kKeyNone) return -1;
@@ -325,7 +336,8 @@ __global__ __launch_bounds__(256) void k_bin_reset(DevTick k, uint32_t* __restri
   __shared__ uint32_t wave_sum[16];
   __shared__ uint32_t carry_s;
   if (threadIdx.x == 0) {
-    *best_key = kKeyNone;
+    best_key[0] = kKeyNone;
+    best_key[1] = kKeyNone;
     *overflow = 0;
   }
   scan_cells(k, cell_count, cell_start, wave_sum, &carry_s);
@@ -710,7 +722,8 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_count(DevTick k, const f
     is_last = (t == (uint32_t)k.bin_blocks - 1) ? 1u : 0u;
     if (is_last) {
       *ticket = 0;            // next tick
-      *best_key = kKeyNone;
+      best_key[0] = kKeyNone;
+      best_key[1] = kKeyNone;
       *overflow = 0;
     }
   }
@@ -1362,7 +1375,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
   __syncthreads();
 
   // ---- phase E: stacked scoring (stacked_scoring_model.cpp:75-93) + argmin ----
-  int64_t key = kKeyNone;
+  int64_t key = kKeyNone, cbits = kKeyNone;
   if (tid < nt) {
     const TrajHead h = head[tid];
     const int li = head[tid].li;
@@ -1371,6 +1384,11 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     if (h.steps > 0) {
       cost = 0.0;
       const float* dr = dist + (size_t)tid * S1;
+      // A collided trajectory skipped phase P: its dist[] row and stick_sum hold nothing.  The
+      // stack may list a path critic BEFORE the collision critic (any plugin order is legal,
+      // mpc_critics_ros.cpp:60-81); its non-negative return is then added and thrown away by
+      // the collision critic's -1 further down the stack, so 0 stands in for it here.
+      const bool dead = cloud_ok && ((need_box && h.hit_box) || (need_mm && h.hit_mm));
       for (int m = 0; m < k.n_critics; ++m) {
         double r = 0.0;
         switch (k.ckind[m]) {
@@ -1383,6 +1401,8 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
           case DDDMR_CRITIC_STICK_PATH:
             if (k.m < 3) {
               r = 10.0;
+            } else if (dead) {
+              r = 0.0;
             } else {
               const double acc = h.stick_sum;
               r = acc / (double)k.m;
@@ -1394,6 +1414,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
             break;
           case DDDMR_CRITIC_TOWARD_GLOBAL_PLAN:
             if (k.m < 3) r = 10.0;
+            else if (dead) r = 0.0;
             else r = (double)dr[h.steps - 1] * k.cw[m];
             break;
           case DDDMR_CRITIC_SHORTEST_ANGLE: {
@@ -1411,6 +1432,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         cost += r;
       }
       key = pack_key(cost, (uint32_t)gi);
+      cbits = cost_bits(cost);
     }
     // cost + sample are read back by the last workgroup: device-scope (write-through)
     // stores, matched by device-scope loads there -- no cache flush needed
@@ -1427,53 +1449,89 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     const bool collided = (need_box && h.hit_box) || (need_mm && h.hit_mm);
     traj_load[li] = (uint32_t)h.walked + (uint32_t)h.steps * (2u + (collided ? 0u : (uint32_t)((k.m + 15) >> 4)));
   }
-  // wave-0 shuffle min-reduction of the packed keys, one atomic per workgroup
+  // Wave-0 min-reduction, one pair of atomics per workgroup.  Two words are reduced: the packed
+  // key (top 40 bits of the cost | inverted index: one atomicMin yields minimum cost AND, among
+  // costs equal in those bits, the highest index) and the cost's full bit pattern.  The decode
+  // below uses the second to make the winner exact.
   if (tid < 64) {
     static_assert(kMaxTile <= 16, "only lanes 0..kMaxTile-1 hold keys");
     {
-      long long kk = (long long)key, o;
+      long long kk = (long long)key, cc = (long long)cbits, o;
       o = dpp_row_shl<8>(kk); kk = o < kk ? o : kk;
       o = dpp_row_shl<4>(kk); kk = o < kk ? o : kk;
       o = dpp_row_shl<2>(kk); kk = o < kk ? o : kk;
       o = dpp_row_shl<1>(kk); kk = o < kk ? o : kk;
+      o = dpp_row_shl<8>(cc); cc = o < cc ? o : cc;
+      o = dpp_row_shl<4>(cc); cc = o < cc ? o : cc;
+      o = dpp_row_shl<2>(cc); cc = o < cc ? o : cc;
+      o = dpp_row_shl<1>(cc); cc = o < cc ? o : cc;
       key = (int64_t)kk;                                   // lane 0: minimum of lanes 0..15
+      cbits = (int64_t)cc;
     }
-    if (tid == 0 && key != kKeyNone) atomicMin((long long*)best_key, (long long)key);
+    if (tid == 0 && key != kKeyNone) {
+      atomicMin((long long*)best_key, (long long)key);
+      atomicMin((long long*)best_key + 1, (long long)cbits);
+    }
   }
   // ---- winner decode by the last workgroup (local_planner.cpp:447-480) ----
   // Placement-independent hand-off: every byte handed over (key, cost, sample,
   // capacity flag) is written with device-scope atomics / write-through stores and
   // read with device-scope loads; waves drain their stores, barrier, one relaxed
-  // device-scope ticket.  The workgroup drawing the last ticket writes the result
+  // device-scope ticket.  Wave 0 of the workgroup drawing the last ticket writes the result
   // straight into host-mapped memory (no finalize launch, no D2H copy).
+  //
+  // Exactness: the reference compares full doubles (`cost_ <= minimum_cost`, :460).  The key's
+  // winner i is the highest index among the costs that share the minimum's top 40 bits; if
+  // cost[i] IS the minimum (its bits equal the reduced cost word -- always, unless two costs
+  // differ by less than 3.7e-9 relative without being equal) then i is also the highest index
+  // among the exactly minimal costs, i.e. the reference's answer.  Otherwise the wave rescans
+  // the shard's costs for the exact minimum (rare; 64 lanes, device-scope loads).
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) {
-    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid < 64) {
+    uint32_t t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     if (t == gridDim.x - 1) {
-      *ticket = 0;
-      DevResult r;
-      r.key = __hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      r.index = key_index(r.key);
-      r.cost = -1.0;
-      r.vx = r.vy = r.wz = 0.f;
-      if (r.index >= 0) {
-        const int li = r.index - k.begin;
-        const unsigned long long cb = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(costs) + li,
-                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.cost = __longlong_as_double((long long)cb);
-        const float* so = reinterpret_cast<const float*>(samples_out + li);
-        r.vx = __hip_atomic_load(so + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.vy = __hip_atomic_load(so + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.wz = __hip_atomic_load(so + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int64_t kmin = __hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int64_t cmin = __hip_atomic_load(best_key + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long* cost_words = reinterpret_cast<const unsigned long long*>(costs);
+      int li = -1;
+      if (kmin != kKeyNone) {
+        li = key_index(kmin) - k.begin;
+        const long long cb = (long long)__hip_atomic_load(cost_words + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cb != (long long)cmin) {
+          int found = -1;
+          for (int i = lane; i < k.n_local; i += 64)
+            if ((long long)__hip_atomic_load(cost_words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (long long)cmin) found = i;
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) found = max(found, __shfl_xor(found, o, 64));
+          li = found;
+        }
       }
-      r.n_binned = cell_start[k.n_cells];
-      r.overflow = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      r.seq = 0;
-      r.pad = 0;
-      *result = r;
-      __threadfence_system();
-      __hip_atomic_store(&result->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (lane == 0) {
+        *ticket = 0;
+        DevResult r;
+        r.index = li >= 0 ? k.begin + li : -1;
+        r.cost = -1.0;
+        r.vx = r.vy = r.wz = 0.f;
+        r.key = kKeyNone;
+        if (li >= 0) {
+          r.cost = __longlong_as_double((long long)cmin);
+          r.key = pack_key(r.cost, (uint32_t)r.index);
+          const float* so = reinterpret_cast<const float*>(samples_out + li);
+          r.vx = __hip_atomic_load(so + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          r.vy = __hip_atomic_load(so + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          r.wz = __hip_atomic_load(so + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        r.n_binned = cell_start[k.n_cells];
+        r.overflow = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.seq = 0;
+        r.pad = 0;
+        *result = r;
+        __threadfence_system();
+        __hip_atomic_store(&result->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
   DDDMR_STAMP(7);

@@ -185,6 +185,29 @@ class LocalPlanner:
         self._check(self._lib.dddmr_rollout_resolve(self._ctx, C.c_int64(reduced_key), C.byref(res)))
         return res
 
+    def winner_words(self, res: Optional[K.RolloutResult] = None):
+        """This rank's two int64 words of the exact multi-rank argmin (cost bits, -index)."""
+        res = res if res is not None else self.last_result
+        w = (C.c_int64 * 2)()
+        self._lib.dddmr_rollout_winner_words(C.byref(res), w)
+        return int(w[0]), int(w[1])
+
+    def resolve_words(self, words) -> K.RolloutResult:
+        """Resolve the global winner from the min-all-reduced slot vector [2 * n_ranks] int64."""
+        words = [int(v) for v in words]
+        arr = (C.c_int64 * len(words))(*words)
+        res = K.RolloutResult()
+        if self.last_result is not None:
+            C.memmove(C.byref(res), C.byref(self.last_result), C.sizeof(res))
+        self._check(self._lib.dddmr_rollout_resolve_words(self._ctx, arr, len(words) // 2, C.byref(res)))
+        return res
+
+    def stream_ceiling(self, nbytes: int = 1 << 30, reps: int = 10):
+        """Measured stream ceilings of this GPU -> (copy GB/s counting read + write, read-only GB/s)."""
+        cp, rd = C.c_double(0.0), C.c_double(0.0)
+        self._check(self._lib.dddmr_rollout_stream_ceiling(self._ctx, nbytes, reps, C.byref(cp), C.byref(rd)))
+        return cp.value, rd.value
+
     # -- per-trajectory outputs of the last tick -----------------------------
     def debug(self):
         """-> (costs[n_local] f64, steps[n_local] i32, samples[n_local,3] f32)"""

@@ -140,10 +140,11 @@ def _finish(rng, parts, n_points):
 
 
 def _corridor_floor(rng, plan, z_off, n_obstacles, n_blocking, half_window=10.0, wall_y=1.8,
-                    height=2.0):
+                    height=2.0, clear_radius=1.1):
     """One floor: corridor walls y = +-wall_y over the 20 m window plus random
     pillars / boxes; centres >= 0.6 m from the plan except n_blocking ones, and
-    never within 1.1 m of the origin (the robot must start collision-free)."""
+    never within clear_radius of the origin (the robot must start collision-free;
+    a larger radius thins the obstacles the sampled trajectories can reach)."""
     parts = [
         _wall_y(rng, wall_y, -half_window, half_window, z_off, z_off + height),
         _wall_y(rng, -wall_y, -half_window, half_window, z_off, z_off + height),
@@ -161,7 +162,7 @@ def _corridor_floor(rng, plan, z_off, n_obstacles, n_blocking, half_window=10.0,
         else:
             cx = rng.uniform(-half_window + 0.5, half_window - 0.5)
             cy = rng.uniform(-wall_y + 0.3, wall_y - 0.3)
-        if math.hypot(cx, cy) < 1.1:
+        if math.hypot(cx, cy) < (clear_radius if not want_block else 1.1):
             continue
         if not want_block and _plan_distance(plan_xy, cx, cy) < 0.6 + 0.35:
             continue
@@ -188,39 +189,58 @@ def cloud_c1(seed: int = 1, n_points: int = 5_000) -> np.ndarray:
     return _finish(rng, parts, n_points)
 
 
-def cloud_c2(seed: int = 2, n_points: int = 100_000) -> np.ndarray:
-    """C2: 20 x 20 m window, corridor walls y = +-1.8 m, 40 pillars/boxes (6
-    blocking the plan), z in [0,2]; side rooms' far walls fill up the window."""
+# Scene layouts.  "r02" (default) is tuned so that about a quarter of the sampled trajectories
+# collide, as SURVEY.md 8d asks ("target ~25 % colliding trajectories"): with the corridor walls at
+# +-1.8 m, every sample with |vy| * sim_time beyond ~1.4 m ends in a wall, which made 69 % (C2) and
+# 86 % (C3) of the round-1 scenes' trajectories collide -- and colliding trajectories are the cheap
+# ones (early exit, no path critics).  "r01" keeps the round-1 layouts for comparison.
+LAYOUTS = {
+    "r02": {"C2": dict(wall_y=4.5, n_obstacles=40, n_blocking=2, clear_radius=1.1),
+            "C3": dict(wall_y=6.0, n_obstacles=48, n_blocking=2, clear_radius=3.7, n_obstacles_other=60)},
+    "r01": {"C2": dict(wall_y=1.8, n_obstacles=40, n_blocking=6, clear_radius=1.1),
+            "C3": dict(wall_y=1.8, n_obstacles=48, n_blocking=6, clear_radius=1.1, n_obstacles_other=48)},
+}
+DEFAULT_LAYOUT = "r02"
+
+
+def cloud_c2(seed: int = 2, n_points: int = 100_000, layout: str = DEFAULT_LAYOUT) -> np.ndarray:
+    """C2: 20 x 20 m window, corridor walls, 40 pillars/boxes (some blocking the plan),
+    z in [0,2]; the window's outer walls fill up the point budget."""
+    L = LAYOUTS[layout]["C2"]
     rng = np.random.Generator(np.random.PCG64(seed))
     plan = s_curve_plan()
-    parts = _corridor_floor(rng, plan, 0.0, 40, 6)
+    parts = _corridor_floor(rng, plan, 0.0, L["n_obstacles"], L["n_blocking"], wall_y=L["wall_y"],
+                            clear_radius=L["clear_radius"])
     # outer walls of the window (beyond the corridor, never reachable)
     parts += [_wall_y(rng, 9.9, -10, 10, 0.0, 2.0), _wall_y(rng, -9.9, -10, 10, 0.0, 2.0)]
     return _finish(rng, parts, n_points)
 
 
-def cloud_c3(seed: int = 3, n_points: int = 500_000) -> np.ndarray:
+def cloud_c3(seed: int = 3, n_points: int = 500_000, layout: str = DEFAULT_LAYOUT) -> np.ndarray:
     """C3: same footprint, three floors (z offsets 0, 3, 6 m; different layouts)
     and the ceiling slabs' undersides at z = 2.6 and 5.6 m."""
+    L = LAYOUTS[layout]["C3"]
     rng = np.random.Generator(np.random.PCG64(seed))
     plan = s_curve_plan()
     parts = []
     for k, z_off in enumerate((0.0, 3.0, 6.0)):
-        parts += _corridor_floor(rng, plan, z_off, 48, 6 if k == 0 else 0)
+        parts += _corridor_floor(rng, plan, z_off, L["n_obstacles"] if k == 0 else L["n_obstacles_other"],
+                                 L["n_blocking"] if k == 0 else 0, wall_y=L["wall_y"],
+                                 clear_radius=L["clear_radius"] if k == 0 else 1.1)
         parts += [_wall_y(rng, 9.9, -10, 10, z_off, z_off + 2.0), _wall_y(rng, -9.9, -10, 10, z_off, z_off + 2.0)]
     parts += [_slab(rng, 2.6, -10, 10, -10, 10, 0.08), _slab(rng, 5.6, -10, 10, -10, 10, 0.08)]
     return _finish(rng, parts, n_points)
 
 
-def bench_scene(cfg: str) -> Scene:
+def bench_scene(cfg: str, layout: str = DEFAULT_LAYOUT) -> Scene:
     """Scene for BASELINE.json config C1..C4 (C4 = C2's cloud, 65536 samples)."""
     b = configs.BENCH[cfg]
     if cfg == "C1":
         cloud = cloud_c1(b["seed"], b["points"])
     elif cfg == "C3":
-        cloud = cloud_c3(b["seed"], b["points"])
+        cloud = cloud_c3(b["seed"], b["points"], layout)
     else:
-        cloud = cloud_c2(b["seed"], b["points"])
+        cloud = cloud_c2(configs.BENCH["C2"]["seed"] if layout != "r01" else b["seed"], b["points"], layout)
     return Scene(cfg, configs.bench_theory(cfg), cloud, s_curve_plan(), tick_input())
 
 

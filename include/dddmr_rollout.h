@@ -19,7 +19,9 @@
  *     ticks (perception mutex local_planner.cpp:498, critics mutex :577); the
  *     library additionally takes an internal mutex per call.  set_cloud /
  *     set_scan may be called from the sensor-callback thread while another
- *     thread ticks (the device cloud is double-buffered).
+ *     thread ticks (the device cloud is triple-buffered: published / being read by
+ *     a tick / free, so a producer never waits for a tick and never overwrites
+ *     what one reads; producers are serialised among themselves).
  *   - the library never runs any of this on the CPU: with no usable HIP device
  *     dddmr_rollout_create fails with DDDMR_ERR_NO_DEVICE.
  */
@@ -33,7 +35,7 @@
 extern "C" {
 #endif
 
-#define DDDMR_ROLLOUT_ABI_VERSION 1
+#define DDDMR_ROLLOUT_ABI_VERSION 2
 #define DDDMR_MAX_CRITICS 8
 #define DDDMR_NAME_LEN 64
 
@@ -264,16 +266,32 @@ int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name,
    (e.g. the previous tick's all-reduce) with the GPU: tick_begin enqueues the
    tick and returns at once, tick_end waits for it and fills the result.  Exactly
    one tick may be pending per context; set_prune_plan / tick / get_* return
-   DDDMR_ERR_STATE while one is.  set_cloud / set_scan stay allowed (they fill the
-   back buffer).  dddmr_rollout_tick == tick_begin + tick_end. */
+   DDDMR_ERR_STATE while one is.  set_cloud / set_scan stay allowed, any number of
+   times, from any thread (they fill a free buffer; the pending tick keeps the
+   observation it started with).  dddmr_rollout_tick == tick_begin + tick_end. */
 int dddmr_rollout_tick_begin(dddmr_rollout_ctx* ctx, const char* theory_name,
                              const dddmr_tick_input* in);
 int dddmr_rollout_tick_end(dddmr_rollout_ctx* ctx, dddmr_rollout_result* out);
 
-/* Multi-rank hosts: after every rank's tick, min-reduce result.key over the
-   ranks (one 8-byte all-reduce) and resolve the winner on every rank. */
+/* Multi-rank hosts: every rank ticks its shard, then ONE small min all-reduce
+   picks the global winner and every rank resolves its command from the index.
+
+   Exact form (use this one): rank r contributes two int64 words, dddmr_rollout_winner_words
+   = { bit pattern of its best cost, -best_index } (INT64_MAX, INT64_MAX when its shard has no
+   acceptable trajectory).  All-reduce with MIN a vector of 2*n_ranks words in which rank r fills
+   slots [2r, 2r+1] and leaves INT64_MAX elsewhere (16*n_ranks bytes, latency-bound), then call
+   dddmr_rollout_resolve_words on every rank: minimum cost compared as full doubles, equal costs
+   -> highest index, exactly the reference's `<=` scan over the whole batch
+   (local_planner.cpp:456-463).
+
+   8-byte form: min-reduce result.key (dddmr_rollout_pack_key) and call dddmr_rollout_resolve.
+   The key carries the top 40 bits of the cost, so across ranks costs closer than 3.7e-9
+   relative resolve to the higher index; inside one shard the winner is always exact. */
 int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key,
                           dddmr_rollout_result* inout);
+void dddmr_rollout_winner_words(const dddmr_rollout_result* r, int64_t words[2]);
+int dddmr_rollout_resolve_words(dddmr_rollout_ctx* ctx, const int64_t* words, int32_t n_ranks,
+                                dddmr_rollout_result* inout);
 
 /* Per-trajectory outputs of the last tick (any pointer may be NULL). */
 int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg);
@@ -294,9 +312,17 @@ int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out,
 
 /* Argmin key: min over keys == minimum cost, ties -> highest index (the
    reference's `<=` scan keeps the LAST minimal trajectory,
-   local_planner.cpp:460-463).  cost < 0 (rejected) -> INT64_MAX. */
+   local_planner.cpp:460-463).  cost < 0 (rejected) or cost > 9999999 (the scan's
+   initial minimum_cost, :452: never accepted) -> INT64_MAX. */
 int64_t dddmr_rollout_pack_key(double cost, uint32_t global_index);
 int32_t dddmr_rollout_key_index(int64_t key); /* -1 for the "none" key */
+
+/* Measurement aid ("a measured stream-copy ceiling on the same GPU"): streams
+   `bytes` (>= 1 GiB recommended: beyond the 256 MB of MALL) `reps` times through a float4 copy
+   kernel and a read-only kernel on the context's device; *copy_gbps counts read + write bytes.
+   Not part of the reference's surface and not on the tick's path. */
+int dddmr_rollout_stream_ceiling(dddmr_rollout_ctx* ctx, size_t bytes, int32_t reps,
+                                 double* copy_gbps, double* read_gbps);
 
 const char* dddmr_rollout_last_error(dddmr_rollout_ctx* ctx);
 const char* dddmr_rollout_version(void);

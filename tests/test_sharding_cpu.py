@@ -45,7 +45,9 @@ def _worker(rank, world, port, which, q):
         o = oracle.tick(sc.theory, sc.cloud, sc.plan, sc.tick, begin=b, end=e)   # the checker scores the shard
         key = sharding.pack_key(o.result.best_cost, max(o.result.best_index, 0))
         red = sharding.all_reduce_key(key)
-        q.put((rank, b, e, key, red))
+        # exact form: (cost bits, -index) slots, one min all-reduce of 2*world words
+        slots = sharding.all_reduce_words(sharding.winner_words(o.result.best_cost, o.result.best_index), rank, world)
+        q.put((rank, b, e, key, red, sharding.reduce_words(slots)))
     finally:
         dist.destroy_process_group()
 
@@ -67,7 +69,26 @@ def test_two_rank_argmin_equals_unsharded(which):
     reduced = {o[4] for o in out}
     assert len(reduced) == 1                       # every rank holds the same winner
     assert sharding.key_index(reduced.pop()) == full.result.best_index
+    exact = {o[5] for o in out}
+    assert exact == {(full.result.best_cost, full.result.best_index)}    # full doubles, same index
     out.sort()
     assert out[0][1] == 0 and out[0][2] == out[1][1] and out[1][2] == full.result.n_samples
     if which == "tie":
         assert full.result.best_index == 1          # the later of two equal minima, on rank 1
+
+
+def test_exact_words_beat_the_40_bit_key_on_near_ties():
+    """Two costs 1e-12 apart on different ranks: the 8-byte key cannot tell them apart (it resolves
+    to the higher index), the slot words do (the reference compares full doubles,
+    local_planner.cpp:460)."""
+    a, b = 1.0, 1.0 + 1e-12
+    ka, kb = sharding.pack_key(a, 3), sharding.pack_key(b, 9)
+    assert sharding.key_index(min(ka, kb)) == 9            # documented limit of the packed key
+    slots = list(sharding.winner_words(a, 3)) + list(sharding.winner_words(b, 9))
+    assert sharding.reduce_words(slots) == (a, 3)
+    # exact tie -> higher index; "none" ranks are ignored; costs above the reference's cap are none
+    slots = list(sharding.winner_words(a, 3)) + list(sharding.winner_words(a, 9)) + list(sharding.winner_words(-1.0, -1))
+    assert sharding.reduce_words(slots) == (a, 9)
+    assert sharding.winner_words(1e7, 2) == (sharding.INT64_MAX, sharding.INT64_MAX)
+    assert sharding.pack_key(1e7, 2) == K.KEY_NONE
+    assert sharding.reduce_words([sharding.INT64_MAX] * 4) == (-1.0, -1)
