@@ -56,6 +56,7 @@ COST_NN_FAIL = -12.0
 COST_NOT_GENERATED = -100.0
 
 KEY_NONE = (1 << 63) - 1
+COMM_ID_BYTES = 128
 
 
 class CriticConfig(C.Structure):
@@ -165,6 +166,9 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_path_blocked",
     "dddmr_rollout_pack_key",
     "dddmr_rollout_key_index",
+    "dddmr_rollout_comm_unique_id",
+    "dddmr_rollout_comm_init",
+    "dddmr_rollout_comm_destroy",
     "dddmr_rollout_stream_ceiling",
     "dddmr_rollout_last_error",
     "dddmr_rollout_version",
@@ -232,6 +236,12 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_pack_key.restype = C.c_int64
     lib.dddmr_rollout_key_index.argtypes = [C.c_int64]
     lib.dddmr_rollout_key_index.restype = C.c_int32
+    lib.dddmr_rollout_comm_unique_id.argtypes = [C.c_void_p]
+    lib.dddmr_rollout_comm_unique_id.restype = C.c_int
+    lib.dddmr_rollout_comm_init.argtypes = [ctx_p, C.c_void_p, C.c_int32, C.c_int32]
+    lib.dddmr_rollout_comm_init.restype = C.c_int
+    lib.dddmr_rollout_comm_destroy.argtypes = [ctx_p]
+    lib.dddmr_rollout_comm_destroy.restype = C.c_int
     lib.dddmr_rollout_stream_ceiling.argtypes = [ctx_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.dddmr_rollout_stream_ceiling.restype = C.c_int
     lib.dddmr_rollout_last_error.argtypes = [ctx_p]

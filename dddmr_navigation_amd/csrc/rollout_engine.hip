@@ -9,6 +9,8 @@
 //
 // Citations are relative to /root/reference/src/dddmr_local_planner/.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only: the library is dlopen()ed by dddmr_rollout_comm_init
 
 #include <algorithm>
 #include <atomic>
@@ -218,6 +220,14 @@ struct dddmr_rollout_ctx {
   // buffer i was published but no wait on cloud_ready[i] has been enqueued on `stream` yet
   bool wait_pending[kCloudBufs] = {false, false, false};
 
+  // multi-rank contexts (dddmr_rollout_comm_init): the library's own RCCL communicator; the tick then
+  // runs k_score -> ncclAllReduce(min) of the ranks' (cost bits, -index) slots -> k_resolve on `stream`
+  ncclComm_t comm = nullptr;
+  int comm_ranks = 0;
+  int64_t* slots_dev = nullptr;      // [2 * comm_ranks] send: own slot written by k_score, INT64_MAX elsewhere
+  int64_t* slots_red = nullptr;      // [2 * comm_ranks] receive
+  DevResult* local_result_dev = nullptr;
+
   std::mutex tick_mu;
   std::mutex err_mu;        // last_error is written by tick and sensor threads alike
   std::string last_error;
@@ -251,6 +261,45 @@ struct dddmr_rollout_ctx {
 namespace {
 
 void release_cloud(dddmr_rollout_ctx* c);
+
+// RCCL entry points, resolved at run time: the engine has no link-time dependency on librccl (hosts
+// that never call dddmr_rollout_comm_init do not need it), and a process that already holds a copy --
+// PyTorch ships its own librccl.so -- shares it instead of loading a second one.
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*get_unique_id)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*error_string)(ncclResult_t) = nullptr;
+  std::string why;
+  bool ok() const { return handle != nullptr; }
+};
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    if (const char* e = std::getenv("DDDMR_RCCL_LIB")) h = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+    for (const char* n : names) {
+      if (h) break;
+      h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    }
+    if (!h) { r.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+    r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
+    r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
+    r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(h, "ncclAllReduce"));
+    r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce || !r.error_string) {
+      r.why = "librccl lacks an expected symbol";
+      return;
+    }
+    r.handle = h;
+  });
+  return r;
+}
 
 int fail(dddmr_rollout_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
@@ -375,6 +424,10 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  if (ctx->comm) (void)rccl().comm_destroy(ctx->comm);
+  if (ctx->slots_dev) (void)hipFree(ctx->slots_dev);
+  if (ctx->slots_red) (void)hipFree(ctx->slots_red);
+  if (ctx->local_result_dev) (void)hipFree(ctx->local_result_dev);
   for (int i = 0; i < kCloudBufs; ++i) {
     if (ctx->cloud_dev[i]) (void)hipFree(ctx->cloud_dev[i]);
     if (ctx->cloud_ready[i]) (void)hipEventDestroy(ctx->cloud_ready[i]);
@@ -1036,21 +1089,32 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
       hipLaunchKernelGGL(k_assign, dim3(k.assign_groups), dim3(kBinThreads), 0, ctx->stream, k, ctx->traj_load, ctx->assign);
   }
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
+  // multi-rank context: k_score leaves the shard's winner on the device (staging record + its slot of
+  // the all-reduce), k_resolve publishes the global one
+  DevResult* score_result = ctx->comm ? ctx->local_result_dev : ctx->result_dev;
+  int64_t* score_words = ctx->comm ? ctx->slots_dev + 2 * rank : nullptr;
   if (k.n_local > 0) {
     const int wgs = k.n_tiles;
     const bool lean = !k.want_minmax && !k.rec_pose;
 #define DDDMR_LAUNCH_SCORE(T, L)                                                                                   \
   hipLaunchKernelGGL((k_score<T, L>), dim3(wgs), dim3(T), lds, ctx->stream, k, ctx->traj_info, ctx->st_sc,        \
                      ctx->st_xy, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,             \
-                     ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, ctx->result_dev, ctx->assign, \
-                     ctx->traj_load)
+                     ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, score_result, ctx->assign, \
+                     ctx->traj_load, score_words)
     if (thr == 512) { if (lean) DDDMR_LAUNCH_SCORE(512, true); else DDDMR_LAUNCH_SCORE(512, false); }
     else            { if (lean) DDDMR_LAUNCH_SCORE(256, true); else DDDMR_LAUNCH_SCORE(256, false); }
 #undef DDDMR_LAUNCH_SCORE
   } else {
-    hipLaunchKernelGGL(k_empty_result, dim3(1), dim3(64), 0, ctx->stream, k, ctx->cell_start, ctx->result_dev);
+    hipLaunchKernelGGL(k_empty_result, dim3(1), dim3(64), 0, ctx->stream, k, ctx->cell_start, score_result, score_words);
   }
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs1, ctx->stream));
+  if (ctx->comm) {
+    const int nrc = rccl().all_reduce(ctx->slots_dev, ctx->slots_red, (size_t)2 * ctx->comm_ranks, ncclInt64, ncclMin,
+                                      ctx->comm, ctx->stream);
+    if (nrc != ncclSuccess) return fail(ctx, DDDMR_ERR_HIP, "ncclAllReduce failed: %s", rccl().error_string((ncclResult_t)nrc));
+    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, ctx->stream, k, ctx->slots_red, ctx->comm_ranks,
+                       ctx->local_result_dev, ctx->axes_dev, ctx->samples_dev, ctx->result_dev);
+  }
   if (timed_all) HIPCHK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
   HIPCHK(ctx, hipGetLastError());
   if (ctx->host_prof) {
@@ -1234,6 +1298,59 @@ int dddmr_rollout_resolve_words(dddmr_rollout_ctx* ctx, const int64_t* words, in
   inout->best_cost = cv.d;
   inout->vx = vx; inout->vy = vy; inout->wz = wz;
   inout->key = pack_key(cv.d, (uint32_t)idx);
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_comm_unique_id(uint8_t id_out[DDDMR_COMM_ID_BYTES]) {
+  static_assert(DDDMR_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "unique id size");
+  if (!id_out) return DDDMR_ERR_BAD_ARG;
+  if (!rccl().ok()) return DDDMR_ERR_NO_DEVICE;
+  ncclUniqueId id;
+  if (rccl().get_unique_id(&id) != ncclSuccess) return DDDMR_ERR_HIP;
+  std::memcpy(id_out, id.internal, DDDMR_COMM_ID_BYTES);
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_comm_init(dddmr_rollout_ctx* ctx, const uint8_t id[DDDMR_COMM_ID_BYTES], int32_t rank, int32_t n_ranks) {
+  if (!ctx || !id) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "comm_init while a tick_begin is pending");
+  if (ctx->comm) return fail(ctx, DDDMR_ERR_STATE, "comm_init: the context already has a communicator");
+  const int world = std::max(1, ctx->cfg.world_size);
+  if (n_ranks != world || rank != std::min(std::max(0, ctx->cfg.rank), world - 1))
+    return fail(ctx, DDDMR_ERR_BAD_ARG, "comm_init: rank %d of %d does not match the context's shard (rank %d of %d)", rank,
+                n_ranks, ctx->cfg.rank, world);
+  if (!rccl().ok()) return fail(ctx, DDDMR_ERR_NO_DEVICE, "comm_init: %s", rccl().why.c_str());
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->slots_dev) { (void)hipFree(ctx->slots_dev); ctx->slots_dev = nullptr; }      // (re-initialisation after comm_destroy)
+  if (ctx->slots_red) { (void)hipFree(ctx->slots_red); ctx->slots_red = nullptr; }
+  if (ctx->local_result_dev) { (void)hipFree(ctx->local_result_dev); ctx->local_result_dev = nullptr; }
+  HIPCHK(ctx, hipMalloc(&ctx->slots_dev, (size_t)2 * n_ranks * sizeof(int64_t)));
+  HIPCHK(ctx, hipMalloc(&ctx->slots_red, (size_t)2 * n_ranks * sizeof(int64_t)));
+  HIPCHK(ctx, hipMalloc(&ctx->local_result_dev, sizeof(DevResult)));
+  std::vector<int64_t> none((size_t)2 * n_ranks, INT64_MAX);     // the other ranks' slots never change
+  HIPCHK(ctx, hipMemcpy(ctx->slots_dev, none.data(), none.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->slots_red, none.data(), none.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  ncclUniqueId uid;
+  std::memcpy(uid.internal, id, DDDMR_COMM_ID_BYTES);
+  ncclComm_t comm = nullptr;
+  const ncclResult_t rc = rccl().comm_init_rank(&comm, n_ranks, uid, rank);     // collective: every rank calls it
+  if (rc != ncclSuccess) return fail(ctx, DDDMR_ERR_HIP, "ncclCommInitRank failed: %s", rccl().error_string(rc));
+  ctx->comm = comm;
+  ctx->comm_ranks = n_ranks;
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_comm_destroy(dddmr_rollout_ctx* ctx) {
+  if (!ctx) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "comm_destroy while a tick_begin is pending");
+  if (!ctx->comm) return DDDMR_OK;
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)rccl().comm_destroy(ctx->comm);
+  ctx->comm = nullptr;
+  ctx->comm_ranks = 0;
   return DDDMR_OK;
 }
 

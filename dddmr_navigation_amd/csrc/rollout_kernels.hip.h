@@ -853,7 +853,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     const Pt3* __restrict__ sorted, double* __restrict__ costs, int32_t* __restrict__ steps_out,
     float4* __restrict__ samples_out, int64_t* __restrict__ best_key, uint32_t* __restrict__ overflow,
     uint32_t* __restrict__ ticket, DevResult* __restrict__ result, const uint32_t* __restrict__ assign,
-    uint32_t* __restrict__ traj_load) {
+    uint32_t* __restrict__ traj_load, int64_t* __restrict__ words_out) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tile = k.tile;
   const int S1 = k.max_steps + 1;
@@ -1529,8 +1529,15 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
         r.seq = 0;
         r.pad = 0;
         *result = r;
-        __threadfence_system();
-        __hip_atomic_store(&result->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (words_out) {
+          // multi-rank context: this shard's (cost bits, -index) slot of the all-reduce that follows on
+          // the stream; `result` then is a device-side staging record and k_resolve tells the host
+          words_out[0] = li >= 0 ? (int64_t)cmin : kKeyNone;
+          words_out[1] = li >= 0 ? -(int64_t)r.index : kKeyNone;
+        } else {
+          __threadfence_system();
+          __hip_atomic_store(&result->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
       }
     }
   }
@@ -1539,7 +1546,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
 
 // n_local == 0 (a rank without samples): result only.
 __global__ void k_empty_result(DevTick k, const uint32_t* __restrict__ cell_start,
-                               DevResult* __restrict__ res) {
+                               DevResult* __restrict__ res, int64_t* __restrict__ words_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   DevResult r;
   r.key = kKeyNone;
@@ -1548,6 +1555,64 @@ __global__ void k_empty_result(DevTick k, const uint32_t* __restrict__ cell_star
   r.vx = r.vy = r.wz = 0.f;
   r.n_binned = cell_start[k.n_cells];
   r.overflow = 0;
+  r.seq = 0;
+  r.pad = 0;
+  *res = r;
+  if (words_out) {
+    words_out[0] = kKeyNone;
+    words_out[1] = kKeyNone;
+    return;
+  }
+  __threadfence_system();
+  __hip_atomic_store(&res->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The command of global sample gi: the sample decode of the rollout's phase A.
+__device__ __forceinline__ void sample_of_index(const DevTick& k, int gi, const float* __restrict__ axes,
+                                                const float4* __restrict__ samples, float* vx, float* vy, float* w) {
+  if (k.list_mode) {
+    const float4 sm = samples[gi];
+    *vx = sm.x; *vy = sm.y; *w = sm.z;
+    return;
+  }
+  const int ith = gi % k.nth;
+  const int r = gi / k.nth;
+  const int iy = r % k.ny;
+  const int ix = r / k.ny;
+  if (k.axes_inline) {
+    *vx = k.axes_inl[ix]; *vy = k.axes_inl[k.ay_ofs + iy]; *w = k.axes_inl[k.ath_ofs + ith];
+  } else {
+    *vx = axes[ix]; *vy = axes[k.ay_ofs + iy]; *w = axes[k.ath_ofs + ith];
+  }
+}
+
+// Multi-rank contexts (dddmr_rollout_comm_init): runs on the tick's stream right after the
+// ncclAllReduce(min) of the ranks' (cost bits, -index) slots.  Minimum cost as full doubles, equal
+// costs -> highest index = the reference's `<=` scan over the whole batch (local_planner.cpp:456-463);
+// the winner's command follows from its index; the result goes to host-mapped memory like k_score's.
+__global__ void k_resolve(DevTick k, const int64_t* __restrict__ slots, int n_ranks, const DevResult* __restrict__ local,
+                          const float* __restrict__ axes, const float4* __restrict__ samples,
+                          DevResult* __restrict__ res) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int64_t c = kKeyNone, ni = kKeyNone;
+  for (int r = 0; r < n_ranks; ++r) {
+    const int64_t cr = slots[2 * r], ir = slots[2 * r + 1];
+    if (cr == kKeyNone) continue;
+    if (cr < c || (cr == c && ir < ni)) { c = cr; ni = ir; }
+  }
+  DevResult r;
+  r.key = kKeyNone;
+  r.index = -1;
+  r.cost = -1.0;
+  r.vx = r.vy = r.wz = 0.f;
+  if (c != kKeyNone) {
+    r.index = (int32_t)(-ni);
+    r.cost = __longlong_as_double((long long)c);
+    r.key = pack_key(r.cost, (uint32_t)r.index);
+    sample_of_index(k, r.index, axes, samples, &r.vx, &r.vy, &r.wz);
+  }
+  r.n_binned = local->n_binned;
+  r.overflow = local->overflow;
   r.seq = 0;
   r.pad = 0;
   *res = r;

@@ -202,6 +202,23 @@ class LocalPlanner:
         self._check(self._lib.dddmr_rollout_resolve_words(self._ctx, arr, len(words) // 2, C.byref(res)))
         return res
 
+    # -- in-library RCCL exchange (multi-rank contexts) ------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = (C.c_uint8 * K.COMM_ID_BYTES)()
+        rc = self._lib.dddmr_rollout_comm_unique_id(buf)
+        if rc != K.OK:
+            raise RolloutError(rc, "dddmr_rollout_comm_unique_id failed (librccl not loadable?)")
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, n_ranks: int):
+        if len(unique_id) != K.COMM_ID_BYTES:
+            raise ValueError("unique id must be 128 bytes")
+        buf = (C.c_uint8 * K.COMM_ID_BYTES)(*unique_id)
+        self._check(self._lib.dddmr_rollout_comm_init(self._ctx, buf, rank, n_ranks))
+
+    def comm_destroy(self):
+        self._check(self._lib.dddmr_rollout_comm_destroy(self._ctx))
+
     def stream_ceiling(self, nbytes: int = 1 << 30, reps: int = 10):
         """Measured stream ceilings of this GPU -> (copy GB/s counting read + write, read-only GB/s)."""
         cp, rd = C.c_double(0.0), C.c_double(0.0)

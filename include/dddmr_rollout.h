@@ -38,6 +38,7 @@ extern "C" {
 #define DDDMR_ROLLOUT_ABI_VERSION 2
 #define DDDMR_MAX_CRITICS 8
 #define DDDMR_NAME_LEN 64
+#define DDDMR_COMM_ID_BYTES 128 /* == NCCL_UNIQUE_ID_BYTES */
 
 /* library status codes (return values) */
 typedef enum {
@@ -292,6 +293,24 @@ int dddmr_rollout_resolve(dddmr_rollout_ctx* ctx, int64_t reduced_key,
 void dddmr_rollout_winner_words(const dddmr_rollout_result* r, int64_t words[2]);
 int dddmr_rollout_resolve_words(dddmr_rollout_ctx* ctx, const int64_t* words, int32_t n_ranks,
                                 dddmr_rollout_result* inout);
+
+/* In-library exchange (SURVEY.md 8b "Context owns ... RCCL communicators", 8e): a C++ host needs no
+   collective code of its own.  One rank calls dddmr_rollout_comm_unique_id (ncclGetUniqueId) and
+   hands the 128 bytes to the others by any means it has; every rank then calls
+   dddmr_rollout_comm_init with the rank / n_ranks its context was created with (collective:
+   ncclCommInitRank, one process per GPU, RCCL over xGMI).  From then on every tick of the context
+   runs, on the context's stream, k_score -> ONE ncclAllReduce(ncclInt64, ncclMin) of the 2*n_ranks
+   slot vector described above -> a resolve kernel, and dddmr_rollout_tick / tick_end return the
+   GLOBAL winner (best_index, exact best_cost, command) on every rank; `key` is the global winner's
+   packed key, n_local / local_begin still describe the shard.  All ranks must tick in lockstep (same
+   theory, same inputs): the all-reduce is a collective.  librccl is loaded at run time
+   (DDDMR_RCCL_LIB overrides the search), so hosts that never call this need no RCCL.
+   dddmr_rollout_comm_destroy returns the context to single-rank results (the host-side
+   resolve_words path keeps working either way). */
+int dddmr_rollout_comm_unique_id(uint8_t id_out[DDDMR_COMM_ID_BYTES]);
+int dddmr_rollout_comm_init(dddmr_rollout_ctx* ctx, const uint8_t id[DDDMR_COMM_ID_BYTES],
+                            int32_t rank, int32_t n_ranks);
+int dddmr_rollout_comm_destroy(dddmr_rollout_ctx* ctx);
 
 /* Per-trajectory outputs of the last tick (any pointer may be NULL). */
 int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg);

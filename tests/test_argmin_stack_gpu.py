@@ -68,11 +68,11 @@ def test_path_critics_ahead_of_collision(scene, stack):
         th = configs.dd_simple_shipped(critics=[_critic(k) for k in stack])
         tick = scenes.tick_input(twist=(0.4, 0.0, 0.1))
     else:
-        sc = scenes.bench_scene("C2")
+        sc = scenes.bench_scene("C2", "r01")                  # the narrow corridor: most sideways samples hit a wall
         cloud = sc.cloud
         th = configs.omni_simple_shipped(critics=[_critic(k) for k in stack], linear_x_sample=6.0,
-                                         linear_y_sample=6.0, angular_z_sample=8.0)
-        tick = scenes.tick_input(twist=(0.3, 0.1, 0.0))
+                                         linear_y_sample=6.0, angular_z_sample=8.0, sim_time=4.0)
+        tick = scenes.tick_input(twist=(0.4, 0.3, 0.0))
     res, costs, steps, smp = tick_and_debug(th, cloud, sc.plan, tick)
     o = oracle.tick(th, cloud, sc.plan, tick, n_threads=8, want_margin=True)
     np.testing.assert_array_equal(steps, o.steps)

@@ -1,0 +1,60 @@
+"""In-library RCCL exchange (dddmr_rollout_comm_init): torch-free, gloo-free self-test with a
+1-rank communicator on the one GPU of the test box -- k_score -> ncclAllReduce(min) of the
+(cost bits, -index) slots -> k_resolve on the context's stream must deliver exactly what the
+single-rank tick delivers.  (More ranks need more GPUs: RCCL refuses two ranks on one device; the
+N > 1 arithmetic is covered by tests/test_sharding_cpu.py and the resolve_words GPU tests.)"""
+import numpy as np
+import pytest
+
+from dddmr_navigation_amd import _capi as K, configs, scenes
+from dddmr_navigation_amd.local_planner import LocalPlanner, RolloutError
+
+pytestmark = pytest.mark.gpu
+
+
+def _fields(r):
+    return (r.planner_state, r.best_index, r.best_cost, r.vx, r.vy, r.wz, r.key, r.n_samples, r.n_local, r.n_points_binned)
+
+
+@pytest.mark.parametrize("scene", ["playground", "C1", "C2", "blocked", "rotate"])
+def test_one_rank_communicator_gives_the_single_rank_result(scene):
+    if scene == "playground":
+        sc = scenes.playground_scene()
+    elif scene == "rotate":
+        sc = scenes.bench_scene("C1")
+        sc.theory = configs.rotate_inplace_shipped("rot", shortest=True)      # explicit sample list
+    else:
+        sc = scenes.bench_scene("C1" if scene == "blocked" else scene)
+    cloud = sc.cloud if scene != "blocked" else np.array([[0.1, 0.0, 0.3, 0]] * 8, dtype=np.float32)
+    name = sc.theory.name.decode()
+    with LocalPlanner([sc.theory], max_points=max(len(cloud), 16)) as lp:
+        lp.set_cloud(cloud)
+        lp.setPlan(sc.plan)
+        plain = _fields(lp.tick(name, sc.tick))
+        costs = lp.debug()[0].copy()
+        lp.comm_init(lp.comm_unique_id(), 0, 1)
+        with pytest.raises(RolloutError):
+            lp.comm_init(lp.comm_unique_id(), 0, 1)            # already has a communicator
+        for _ in range(3):
+            assert _fields(lp.tick(name, sc.tick)) == plain
+            np.testing.assert_array_equal(lp.debug()[0], costs)
+        lp.tick_begin(name, sc.tick)
+        assert _fields(lp.tick_end()) == plain
+        if plain[1] >= 0:
+            assert len(lp.best_poses()) > 0
+        lp.comm_destroy()
+        assert _fields(lp.tick(name, sc.tick)) == plain
+        lp.comm_init(lp.comm_unique_id(), 0, 1)                # and again after a destroy
+        assert _fields(lp.tick(name, sc.tick)) == plain
+    if scene == "blocked":
+        assert plain[0] == K.ALL_TRAJECTORIES_FAIL and plain[1] == -1
+
+
+def test_comm_init_checks_the_shard():
+    sc = scenes.bench_scene("C1")
+    with LocalPlanner([sc.theory], rank=1, world_size=2) as lp:
+        with pytest.raises(RolloutError) as e:
+            lp.comm_init(lp.comm_unique_id(), 0, 2)            # context is rank 1
+        assert e.value.code == K.ERR_BAD_ARG
+        with pytest.raises(RolloutError):
+            lp.comm_init(lp.comm_unique_id(), 1, 3)            # context's world is 2

@@ -291,11 +291,13 @@ def test_golden_c3_subrange():
     re-score a slice and compare with the frozen vector."""
     g = np.load(os.path.join(GOLD, "F8_C3.npz"))
     sc = scenes.bench_scene("C3")
-    b, e = 9900, 10156
+    b, e = 11400, 11656                     # the slice that holds the frozen winner (11536)
     o = oracle.tick(sc.theory, sc.cloud, sc.plan, sc.tick, begin=b, end=e, n_threads=4)
     np.testing.assert_array_equal(o.costs, g["costs"][b:e])
     np.testing.assert_array_equal(o.steps, g["steps"][b:e])
-    assert int(g["summary"][1]) == 9999 and o.result.best_index == 9999
+    assert int(g["summary"][1]) == 11536 and o.result.best_index == 11536
+    # SURVEY 8d: about a quarter of the C3 trajectories collide (round 1's scene: 86 %)
+    assert 0.2 <= float((g["costs"] == -1.0).mean()) <= 0.3
 
 
 def test_feed_oracle_voxel_centroids():

@@ -1,10 +1,16 @@
 """Summarise rocprofv3 CSV output of tools/profile.sh into profiles/<tag>_*.
-usage: python tools/summarize_profile.py <tag> [workload]"""
+usage: python tools/summarize_profile.py <tag> [workload] [round]
+
+Besides the per-tag files it maintains three per-round tables keyed by workload, which bench.py
+reads for the workload it ran: profiles/traffic.json (HBM bytes per k_score launch),
+profiles/<round>_pmc.json (what binds k_score) and profiles/<round>_kernel_avg.json (rocprofv3's
+average kernel durations, to be compared with bench.py's HIP-event time)."""
 import csv, glob, json, os, sys
 from collections import defaultdict
 
 tag = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else "C2"
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r02"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
@@ -58,6 +64,38 @@ if "FETCH_SIZE" in ks and "WRITE_SIZE" in ks:
                "note": "FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B), WRITE_SIZE as is; separate --pmc passes"}
     tp = os.path.join(dst, "traffic.json")
     allt = json.load(open(tp)) if os.path.exists(tp) else {}
+    traffic["profile"] = tag
     allt[workload] = traffic
     json.dump(allt, open(tp, "w"), indent=1)
     print("traffic", traffic)
+
+
+def update(path, key, value):
+    allv = json.load(open(path)) if os.path.exists(path) else {}
+    allv[key] = value
+    json.dump(allv, open(path, "w"), indent=1, sort_keys=True)
+
+
+# rocprofv3's average durations (ms) of the tick's kernels for this workload
+if rows:
+    avg = {short(r["Name"]) + "_ms": round(float(r["AverageNs"]) * 1e-6, 6) for r in rows if short(r["Name"]).startswith("k_")}
+    avg["source"] = f"profiles/{tag}_kernel_stats.csv"
+    update(os.path.join(dst, f"{rnd}_kernel_avg.json"), workload, avg)
+    print("kernel averages", avg)
+
+# what binds k_score: SQ_* counters count quad-cycles (MI355X_MICROARCH.md); WAIT_ANY + WAIT_INST_ANY +
+# ACTIVE_INST_ANY ~ WAVE_CYCLES.  VALU busy = VALU issue cycles over the SIMD-cycles of the launch
+# (1024 SIMDs x rocprofv3's average duration x 2.4 GHz peak clock: a lower bound of the share).
+if "SQ_WAVE_CYCLES" in ks and rows:
+    dur_ns = next((float(r["AverageNs"]) for r in rows if short(r["Name"]) == "k_score"), None)
+    lim = {
+        "waves_waiting_frac": round(ks["SQ_WAIT_ANY"] / ks["SQ_WAVE_CYCLES"], 4),
+        "issue_stall_frac": round(ks["SQ_WAIT_INST_ANY"] / ks["SQ_WAVE_CYCLES"], 4),
+        "issuing_frac": round(ks["SQ_ACTIVE_INST_ANY"] / ks["SQ_WAVE_CYCLES"], 4),
+        "valu_busy_frac": round(4.0 * ks["SQ_ACTIVE_INST_VALU"] / (dur_ns * 2.4 * 1024), 4) if dur_ns else None,
+        "lds_bank_conflict_per_lds_active": round(ks.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(ks.get("SQ_ACTIVE_INST_LDS", 1.0), 1.0), 3),
+        "l2_hit_rate": round(ks["TCC_HIT_sum"] / max(ks["TCC_HIT_sum"] + ks["TCC_MISS_sum"], 1.0), 4) if "TCC_HIT_sum" in ks else None,
+        "valu_insts_per_launch": ks.get("SQ_INSTS_VALU"), "waves_per_launch": ks.get("SQ_WAVES"),
+        "k_score_avg_ns": dur_ns, "source": f"profiles/{tag}_pmc.json (separate --pmc passes)"}
+    update(os.path.join(dst, f"{rnd}_pmc.json"), workload, lim)
+    print("limiter", lim)
