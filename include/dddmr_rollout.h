@@ -336,6 +336,64 @@ int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out,
 int64_t dddmr_rollout_pack_key(double cost, uint32_t global_index);
 int32_t dddmr_rollout_key_index(int64_t key); /* -1 for the "none" key */
 
+/* ---------------------------------------------------------------------------------------------
+   Global-mode marking / clearing layer: MultiLayerSpinningLidar::selfClear /
+   selfMark with is_local_planner = false
+   (dddmr_perception_3d/plugins/multilayer_spinning_lidar.cpp:306-628, isinLidarObservation :682-746,
+   getCastingPointCloud :630-651) and the cluster store Marking::addPCPtr / removePCPtr /
+   computeMinDistanceFromObstacle2GroundNodes (plugins/cluster_marking.cpp:49-138) with its
+   DynamicGraph (src/graph/dynamic_graph.cpp).  The persistent voxel -> cluster store, the dGraph
+   (per-ground-node obstacle distance) and the lethal set live on the device.
+
+   One dddmr_rollout_marking_update() = one StackedPerception::doClear_then_Mark() pass of the lidar
+   plugin (src/stacked_perception.cpp:72-90): selfClear against the PREVIOUS update's observation
+   and the current sensor pose, then selfMark of the current observation.  The observation is the
+   context's current aggregate cloud in the global frame -- what dddmr_rollout_set_scan leaves on
+   the device (pcl_msg_gbl_, :322-323) or dddmr_rollout_set_cloud uploaded.
+   Parameters carry the plugin's YAML names (multilayer_spinning_lidar.cpp:73-139) and the node's
+   inscribed_radius / inflation_radius / max_obstacle_distance. */
+typedef struct {
+  double xy_resolution, height_resolution;
+  double marking_height, perception_window_size;
+  double vertical_FOV_top, vertical_FOV_bottom;                 /* degrees */
+  double scan_effective_positive_start, scan_effective_positive_end;
+  double scan_effective_negative_start, scan_effective_negative_end;
+  double euclidean_cluster_extraction_tolerance;
+  int32_t euclidean_cluster_extraction_min_cluster_size;
+  int32_t reserved;
+  double segmentation_ignore_ratio;
+  double inscribed_radius, inflation_radius, max_obstacle_distance;
+  uint32_t max_markings;        /* capacity of the persistent store (alive + cleared-but-not-reused slots) */
+  uint32_t max_cluster_points;  /* capacity of the pool of stored cluster points (0.2 m downsampled) */
+} dddmr_marking_config;
+
+typedef struct {
+  uint32_t n_observation;   /* points of the observation this update marked */
+  uint32_t n_clusters;      /* Euclidean clusters found in it */
+  uint32_t n_marked;        /* clusters stored by Marking::addPCPtr */
+  uint32_t n_in_window;     /* stored markings selfClear looked at */
+  uint32_t n_cleared;       /* ... of which removePCPtr'ed */
+  uint32_t n_alive;         /* markings alive after the update */
+  float clear_ms, mark_ms;  /* HIP-event times of the two halves */
+} dddmr_marking_stats;
+
+/* ground = shared_data_->pcl_ground_ (the nodes of the dGraph, kdtree_ground_), map =
+   shared_data_->pcl_map_ (kdtree_map_, the static layer's cloud); both x y z records `stride`
+   bytes apart, copied to the device once.  Also initialises the dGraph (resetdGraph, :831-839). */
+int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_config* cfg,
+                                 const float* ground_xyz, size_t n_ground, size_t ground_stride_bytes,
+                                 const float* map_xyz, size_t n_map, size_t map_stride_bytes);
+int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sensor[7],
+                                 const double T_gbl_base[7], dddmr_marking_stats* stats);
+/* resetdGraph: empty store, dGraph back to max_obstacle_distance. */
+int dddmr_rollout_marking_reset(dddmr_rollout_ctx* ctx);
+/* Alive markings as voxel keys (x y z ints, xyz_out[n][3]); call with NULL for the count. */
+int dddmr_rollout_marking_get_voxels(dddmr_rollout_ctx* ctx, int32_t* xyz_out, size_t capacity, size_t* n);
+/* dGraph values of ground nodes 0..n_ground (DynamicGraph::initial fills n + 1 entries) and the
+   lethal set (lethal_map_ keys) as one byte per ground node. */
+int dddmr_rollout_marking_get_dgraph(dddmr_rollout_ctx* ctx, double* values_out, size_t capacity);
+int dddmr_rollout_marking_get_lethal(dddmr_rollout_ctx* ctx, uint8_t* flags_out, size_t capacity);
+
 /* Measurement aid ("a measured stream-copy ceiling on the same GPU"): streams
    `bytes` (>= 1 GiB recommended: beyond the 256 MB of MALL) `reps` times through a float4 copy
    kernel and a read-only kernel on the context's device; *copy_gbps counts read + write bytes.

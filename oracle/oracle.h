@@ -53,6 +53,25 @@ int oracle_feed(const float* scan, size_t n, size_t stride_bytes, const double T
                 const double T_gbl_base[7], double window, double height, float* out_xyz,
                 size_t capacity, size_t* n_out);
 
+/* ---- global-mode marking / clearing layer (oracle_marking.cpp) ---- */
+typedef dddmr_marking_stats oracle_marking_stats;
+typedef struct oracle_marking oracle_marking;
+oracle_marking* oracle_marking_create(const dddmr_marking_config* cfg, const float* ground_xyz, size_t n_ground,
+                                      size_t ground_stride_bytes, const float* map_xyz, size_t n_map,
+                                      size_t map_stride_bytes);
+void oracle_marking_destroy(oracle_marking* m);
+void oracle_marking_reset(oracle_marking* m);
+int oracle_marking_update(oracle_marking* m, const float* obs_gbl_xyz, size_t n, const double T_base_sensor[7],
+                          const double T_gbl_base[7], oracle_marking_stats* stats);
+size_t oracle_marking_get_voxels(oracle_marking* m, int32_t* xyz_out, size_t capacity);
+size_t oracle_marking_get_dgraph(oracle_marking* m, double* out, size_t capacity);
+size_t oracle_marking_get_lethal(oracle_marking* m, uint8_t* flags, size_t capacity);
+size_t oracle_marking_get_decisions(oracle_marking* m, int which, int32_t* voxels, float* margins, uint8_t* flags,
+                                    size_t capacity);
+int oracle_in_lidar_observation(const dddmr_marking_config* cfg, const double T_base_sensor[7],
+                                const double T_gbl_base[7], const float* pts_xyz, size_t n, uint8_t* inside,
+                                float* margin);
+
 #ifdef __cplusplus
 }
 #endif
