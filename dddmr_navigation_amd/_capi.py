@@ -138,6 +138,32 @@ class RolloutResult(C.Structure):
     ]
 
 
+class MarkingConfig(C.Structure):
+    """dddmr_marking_config: the lidar plugin's global-mode parameters
+    (dddmr_perception_3d/plugins/multilayer_spinning_lidar.cpp:73-139) + the node's radii."""
+    _fields_ = [
+        ("xy_resolution", C.c_double), ("height_resolution", C.c_double),
+        ("marking_height", C.c_double), ("perception_window_size", C.c_double),
+        ("vertical_FOV_top", C.c_double), ("vertical_FOV_bottom", C.c_double),
+        ("scan_effective_positive_start", C.c_double), ("scan_effective_positive_end", C.c_double),
+        ("scan_effective_negative_start", C.c_double), ("scan_effective_negative_end", C.c_double),
+        ("euclidean_cluster_extraction_tolerance", C.c_double),
+        ("euclidean_cluster_extraction_min_cluster_size", C.c_int32),
+        ("reserved", C.c_int32),
+        ("segmentation_ignore_ratio", C.c_double),
+        ("inscribed_radius", C.c_double), ("inflation_radius", C.c_double), ("max_obstacle_distance", C.c_double),
+        ("max_markings", C.c_uint32), ("max_cluster_points", C.c_uint32),
+    ]
+
+
+class MarkingStats(C.Structure):
+    _fields_ = [
+        ("n_observation", C.c_uint32), ("n_clusters", C.c_uint32), ("n_marked", C.c_uint32),
+        ("n_in_window", C.c_uint32), ("n_cleared", C.c_uint32), ("n_alive", C.c_uint32),
+        ("clear_ms", C.c_float), ("mark_ms", C.c_float),
+    ]
+
+
 class RolloutDebug(C.Structure):
     _fields_ = [
         ("costs", C.POINTER(C.c_double)),
@@ -169,6 +195,12 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_comm_unique_id",
     "dddmr_rollout_comm_init",
     "dddmr_rollout_comm_destroy",
+    "dddmr_rollout_marking_create",
+    "dddmr_rollout_marking_update",
+    "dddmr_rollout_marking_reset",
+    "dddmr_rollout_marking_get_voxels",
+    "dddmr_rollout_marking_get_dgraph",
+    "dddmr_rollout_marking_get_lethal",
     "dddmr_rollout_stream_ceiling",
     "dddmr_rollout_last_error",
     "dddmr_rollout_version",
@@ -242,6 +274,19 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_comm_init.restype = C.c_int
     lib.dddmr_rollout_comm_destroy.argtypes = [ctx_p]
     lib.dddmr_rollout_comm_destroy.restype = C.c_int
+    lib.dddmr_rollout_marking_create.argtypes = [ctx_p, C.POINTER(MarkingConfig), C.c_void_p, C.c_size_t, C.c_size_t,
+                                                 C.c_void_p, C.c_size_t, C.c_size_t]
+    lib.dddmr_rollout_marking_create.restype = C.c_int
+    lib.dddmr_rollout_marking_update.argtypes = [ctx_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(MarkingStats)]
+    lib.dddmr_rollout_marking_update.restype = C.c_int
+    lib.dddmr_rollout_marking_reset.argtypes = [ctx_p]
+    lib.dddmr_rollout_marking_reset.restype = C.c_int
+    lib.dddmr_rollout_marking_get_voxels.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.dddmr_rollout_marking_get_voxels.restype = C.c_int
+    lib.dddmr_rollout_marking_get_dgraph.argtypes = [ctx_p, C.c_void_p, C.c_size_t]
+    lib.dddmr_rollout_marking_get_dgraph.restype = C.c_int
+    lib.dddmr_rollout_marking_get_lethal.argtypes = [ctx_p, C.c_void_p, C.c_size_t]
+    lib.dddmr_rollout_marking_get_lethal.restype = C.c_int
     lib.dddmr_rollout_stream_ceiling.argtypes = [ctx_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.dddmr_rollout_stream_ceiling.restype = C.c_int
     lib.dddmr_rollout_last_error.argtypes = [ctx_p]

@@ -1,0 +1,535 @@
+// marking_host.hip.h -- host side of the global-mode marking / clearing layer (included by
+// rollout_engine.hip after the context and its helpers are defined): device state, the per-update
+// launch sequence and the dddmr_rollout_marking_* entry points of include/dddmr_rollout.h.
+#pragma once
+
+#include "marking.hip.h"
+
+namespace {
+
+using namespace dddmr;
+
+struct GridBuf {              // a PointGrid with its storage
+  PointGrid g;
+  uint32_t cap_cells = 0, cap_points = 0;
+};
+
+struct MarkingState {
+  dddmr_marking_config cfg{};
+  uint32_t n_ground = 0, n_map = 0, table = 0, pool_cap = 0, max_obs = 0;
+  float4 *ground_pts = nullptr, *map_pts = nullptr;
+  GridBuf ground, map, obs[2];
+  int prev = -1;              // obs[] entry holding pcl_msg_gbl_ of the last selfMark, -1 = none yet
+  uint32_t n_prev = 0;
+  float4* obs_copy[2] = {nullptr, nullptr};
+  MarkStore store{};
+  float4* pool_alt = nullptr;
+  uint32_t pool_used_host = 0;
+  // scratch of one update (sized for max_obs)
+  uint2* gslot = nullptr;
+  uint32_t* parent = nullptr;
+  unsigned long long *keys_a = nullptr, *keys_b = nullptr, *keys1 = nullptr;
+  uint32_t *vals_a = nullptr, *vals_b = nullptr, *flags = nullptr, *incl = nullptr, *cid_incl = nullptr;
+  float4 *ds = nullptr, *proj = nullptr, *gen = nullptr;
+  uint32_t *ds_first = nullptr, *pool_ofs = nullptr, *compact_sizes = nullptr, *compact_ofs = nullptr;
+  ClusterArrays cl{};
+  MarkCounters* counters = nullptr;        // device
+  uint32_t* n_groups = nullptr;            // [2] device: groups of the 0.2 m and of the 0.1 m VoxelGrid
+  void* temp = nullptr;
+  size_t temp_bytes = 0;
+  hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  uint32_t seq = 0;
+};
+
+void free_grid(GridBuf& b) {
+  if (b.g.cell_start) (void)hipFree(b.g.cell_start);
+  if (b.g.sorted) (void)hipFree(b.g.sorted);
+  b = GridBuf();
+}
+
+void marking_free(MarkingState* m) {
+  if (!m) return;
+  void* p[] = {m->ground_pts, m->map_pts, m->obs_copy[0], m->obs_copy[1], m->store.keys, m->store.alive, m->store.pts_ofs,
+               m->store.pts_n, m->store.removed_seq, m->store.owner, m->store.pool, m->pool_alt, m->store.dgraph, m->store.lethal,
+               m->gslot, m->parent, m->keys_a, m->keys_b, m->keys1, m->vals_a, m->vals_b, m->flags, m->incl, m->cid_incl, m->ds,
+               m->proj, m->gen, m->ds_first, m->pool_ofs, m->compact_sizes, m->compact_ofs, m->cl.start, m->cl.size, m->cl.centroid,
+               m->cl.state, m->cl.ds_count, m->cl.gen_first, m->cl.gen_count, m->cl.slot, m->cl.vkey, m->counters, m->n_groups,
+               m->temp};
+  for (void* q : p)
+    if (q) (void)hipFree(q);
+  free_grid(m->ground); free_grid(m->map); free_grid(m->obs[0]); free_grid(m->obs[1]);
+  if (m->e0) (void)hipEventDestroy(m->e0);
+  if (m->e1) (void)hipEventDestroy(m->e1);
+  if (m->e2) (void)hipEventDestroy(m->e2);
+  delete m;
+}
+
+// Grid geometry over [lo, hi] with the wanted cell sizes, coarsened until it fits `cap_cells`.
+void grid_shape(PointGrid& g, const float lo[3], const float hi[3], float cell_xy, float cell_z, uint32_t cap_cells) {
+  for (;;) {
+    g.nx = std::max(1, (int)std::ceil((hi[0] - lo[0]) / cell_xy) + 1);
+    g.ny = std::max(1, (int)std::ceil((hi[1] - lo[1]) / cell_xy) + 1);
+    g.nz = std::max(1, (int)std::ceil((hi[2] - lo[2]) / cell_z) + 1);
+    if ((uint64_t)g.nx * g.ny * g.nz <= cap_cells) break;
+    cell_xy *= 1.3f;
+    cell_z *= 1.3f;
+  }
+  g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
+  g.inv_xy = 1.0f / cell_xy;
+  g.inv_z = 1.0f / cell_z;
+}
+
+int grid_alloc(dddmr_rollout_ctx* ctx, GridBuf& b, uint32_t cap_cells, uint32_t cap_points) {
+  b.cap_cells = cap_cells;
+  b.cap_points = cap_points;
+  HIPCHK(ctx, hipMalloc(&b.g.cell_start, ((size_t)cap_cells + 1) * sizeof(uint32_t)));
+  HIPCHK(ctx, hipMalloc(&b.g.sorted, (size_t)std::max<uint32_t>(cap_points, 1) * sizeof(float4)));
+  return DDDMR_OK;
+}
+
+// count -> exclusive scan -> scatter on `stream`; `counts` doubles as cell_start
+int grid_build(dddmr_rollout_ctx* ctx, MarkingState* m, GridBuf& b, const float4* pts, uint32_t n, uint2* slot, hipStream_t stream) {
+  PointGrid& g = b.g;
+  g.n = n;
+  const size_t cells = (size_t)g.nx * g.ny * g.nz;
+  HIPCHK(ctx, hipMemsetAsync(g.cell_start, 0, (cells + 1) * sizeof(uint32_t), stream));
+  if (n == 0) return DDDMR_OK;
+  hipLaunchKernelGGL(k_grid_count, dim3((n + 255) / 256), dim3(256), 0, stream, g, pts, g.cell_start, slot);
+  size_t need = m->temp_bytes;
+  HIPCHK(ctx, rocprim::exclusive_scan(m->temp, need, g.cell_start, g.cell_start, 0u, cells + 1, rocprim::plus<uint32_t>(), stream));
+  hipLaunchKernelGGL(k_grid_scatter, dim3((n + 255) / 256), dim3(256), 0, stream, g, pts, slot);
+  return DDDMR_OK;
+}
+
+void quat_rotate_z(const double q[4], double out[3]) {   // tf2::quatRotate(q, (0, 0, 1)); q = x y z w
+  // q * v
+  const double ax = q[1] * 1.0, ay = -q[0] * 1.0, az = q[3] * 1.0, aw = -q[2] * 1.0;   // (w*0 + y*1 - z*0, w*0 + z*0 - x*1, w*1 + x*0 - y*0, -x*0 - y*0 - z*1)
+  // (q * v) * q^-1, q^-1 = (-x, -y, -z, w)
+  const double bx = -q[0], by = -q[1], bz = -q[2], bw = q[3];
+  out[0] = aw * bx + ax * bw + ay * bz - az * by;
+  out[1] = aw * by + ay * bw + az * bx - ax * bz;
+  out[2] = aw * bz + az * bw + ax * by - ay * bx;
+}
+
+// Eigen quaternion of a rotation matrix (row-major R), as tf2::eigenToTransform forms trans_gbl2s_'s rotation
+void rot_to_quat(const double R[9], double q[4]) {
+  double t = R[0] + R[4] + R[8];
+  if (t > 0.0) {
+    t = std::sqrt(t + 1.0);
+    q[3] = 0.5 * t;
+    t = 0.5 / t;
+    q[0] = (R[7] - R[5]) * t;
+    q[1] = (R[2] - R[6]) * t;
+    q[2] = (R[3] - R[1]) * t;
+  } else {
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(R[4 * i] - R[4 * j] - R[4 * k] + 1.0);
+    q[i] = 0.5 * t;
+    t = 0.5 / t;
+    q[3] = (R[3 * k + j] - R[3 * j + k]) * t;
+    q[j] = (R[3 * j + i] + R[3 * i + j]) * t;
+    q[k] = (R[3 * k + i] + R[3 * i + k]) * t;
+  }
+}
+// tf2 Matrix3x3::setRotation(q), row-major
+void tf2_set_rotation(const double q[4], double R[9]) {
+  const double d = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const double s = 2.0 / d;
+  const double xs = q[0] * s, ys = q[1] * s, zs = q[2] * s;
+  const double wx = q[3] * xs, wy = q[3] * ys, wz = q[3] * zs;
+  const double xx = q[0] * xs, xy = q[0] * ys, xz = q[0] * zs;
+  const double yy = q[1] * ys, yz = q[1] * zs, zz = q[2] * zs;
+  R[0] = 1.0 - (yy + zz); R[1] = xy - wz; R[2] = xz + wy;
+  R[3] = xy + wz; R[4] = 1.0 - (xx + zz); R[5] = yz - wx;
+  R[6] = xz - wy; R[7] = yz + wx; R[8] = 1.0 - (xx + yy);
+}
+
+int upload_static(dddmr_rollout_ctx* ctx, MarkingState* m, GridBuf& b, float4** dev, const float* xyz, size_t n, size_t stride_bytes,
+                  float cell_xy, float cell_z) {
+  std::vector<float4> h(std::max<size_t>(n, 1));
+  float lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+  const size_t sf = stride_bytes / sizeof(float);
+  for (size_t i = 0; i < n; ++i) {
+    const float* p = xyz + i * sf;
+    h[i] = make_float4(p[0], p[1], p[2], 0.f);
+    for (int a = 0; a < 3; ++a) {
+      lo[a] = i ? std::min(lo[a], p[a]) : p[a];
+      hi[a] = i ? std::max(hi[a], p[a]) : p[a];
+    }
+  }
+  HIPCHK(ctx, hipMalloc(dev, h.size() * sizeof(float4)));
+  HIPCHK(ctx, hipMemcpy(*dev, h.data(), h.size() * sizeof(float4), hipMemcpyHostToDevice));
+  grid_shape(b.g, lo, hi, cell_xy, cell_z, 1u << 22);
+  const int rc = grid_alloc(ctx, b, (uint32_t)((size_t)b.g.nx * b.g.ny * b.g.nz), (uint32_t)n);
+  if (rc != DDDMR_OK) return rc;
+  uint2* slot = nullptr;
+  HIPCHK(ctx, hipMalloc(&slot, std::max<size_t>(n, 1) * sizeof(uint2)));
+  const int rb = grid_build(ctx, m, b, *dev, (uint32_t)n, slot, ctx->stream);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  (void)hipFree(slot);
+  return rb;
+}
+
+int marking_reset_locked(dddmr_rollout_ctx* ctx);
+
+}  // namespace
+
+extern "C" {
+
+int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_config* cfg, const float* ground_xyz,
+                                 size_t n_ground, size_t ground_stride_bytes, const float* map_xyz, size_t n_map,
+                                 size_t map_stride_bytes) {
+  if (!ctx || !cfg) return DDDMR_ERR_BAD_ARG;
+  if ((n_ground && (!ground_xyz || ground_stride_bytes < 12 || ground_stride_bytes % 4)) ||
+      (n_map && (!map_xyz || map_stride_bytes < 12 || map_stride_bytes % 4)))
+    return fail(ctx, DDDMR_ERR_BAD_ARG, "marking_create: bad cloud pointer / stride");
+  if (!(cfg->xy_resolution > 0) || !(cfg->height_resolution > 0) || !(cfg->euclidean_cluster_extraction_tolerance > 0) ||
+      !(cfg->inflation_radius > 0) || cfg->max_markings == 0 || cfg->max_cluster_points == 0)
+    return fail(ctx, DDDMR_ERR_BAD_ARG, "marking_create: resolutions, tolerance, inflation radius and capacities must be positive");
+  if (n_ground >= (1u << 30) || cfg->max_markings > (1u << 24)) return fail(ctx, DDDMR_ERR_CAPACITY, "marking_create: too large");
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "marking_create while a tick_begin is pending");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->marking) { marking_free(ctx->marking); ctx->marking = nullptr; }
+  auto* m = new MarkingState();
+  ctx->marking = m;
+  m->cfg = *cfg;
+  m->n_ground = (uint32_t)n_ground;
+  m->n_map = (uint32_t)n_map;
+  m->max_obs = ctx->cfg.max_points;
+  uint32_t table = 1024;
+  while (table < 2 * cfg->max_markings) table <<= 1;
+  m->table = table;
+  m->pool_cap = cfg->max_cluster_points;
+  auto init = [&]() -> int {
+    const size_t N = m->max_obs;
+    // rocPRIM temporary storage: the largest request among the sorts and scans used below
+    {
+      size_t a = 0, b = 0, c = 0;
+      unsigned long long* k = nullptr;
+      uint32_t* v = nullptr;
+      HIPCHK(ctx, rocprim::radix_sort_keys(nullptr, a, k, k, N, 0, 40, ctx->stream));
+      HIPCHK(ctx, rocprim::radix_sort_pairs(nullptr, b, k, k, v, v, N, 0, 62, ctx->stream));
+      HIPCHK(ctx, rocprim::exclusive_scan(nullptr, c, v, v, 0u, (size_t)(1u << 22) + 1, rocprim::plus<uint32_t>(), ctx->stream));
+      m->temp_bytes = std::max({a, b, c, (size_t)4096}) + 256;
+      HIPCHK(ctx, hipMalloc(&m->temp, m->temp_bytes));
+    }
+    int rc = upload_static(ctx, m, m->ground, &m->ground_pts, ground_xyz, n_ground, ground_stride_bytes, 0.5f, 1e6f);
+    if (rc != DDDMR_OK) return rc;
+    rc = upload_static(ctx, m, m->map, &m->map_pts, map_xyz, n_map, map_stride_bytes, 0.25f, 0.25f);
+    if (rc != DDDMR_OK) return rc;
+    for (int i = 0; i < 2; ++i) {
+      rc = grid_alloc(ctx, m->obs[i], 1u << 21, (uint32_t)N);
+      if (rc != DDDMR_OK) return rc;
+      HIPCHK(ctx, hipMalloc(&m->obs_copy[i], N * sizeof(float4)));
+    }
+    MarkStore& s = m->store;
+    HIPCHK(ctx, hipMalloc(&s.keys, (size_t)table * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMalloc(&s.alive, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&s.pts_ofs, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&s.pts_n, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&s.removed_seq, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&s.owner, (size_t)table * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMalloc(&s.pool, (size_t)m->pool_cap * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&m->pool_alt, (size_t)m->pool_cap * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&s.dgraph, ((size_t)n_ground + 1) * sizeof(double)));
+    HIPCHK(ctx, hipMalloc(&s.lethal, (size_t)n_ground + 1));
+    HIPCHK(ctx, hipMalloc(&m->gslot, N * sizeof(uint2)));
+    HIPCHK(ctx, hipMalloc(&m->parent, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->keys_a, N * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMalloc(&m->keys_b, N * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMalloc(&m->keys1, N * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMalloc(&m->vals_a, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->vals_b, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->flags, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->incl, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->cid_incl, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->ds, N * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&m->proj, N * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&m->gen, N * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&m->ds_first, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->pool_ofs, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->compact_sizes, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->compact_ofs, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->cl.start, (N + 1) * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->cl.size, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->cl.centroid, N * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&m->cl.state, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->cl.ds_count, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->cl.gen_first, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->cl.gen_count, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->cl.slot, N * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->cl.vkey, 3 * N * sizeof(int)));
+    HIPCHK(ctx, hipMalloc(&m->counters, sizeof(MarkCounters)));
+    HIPCHK(ctx, hipMalloc(&m->n_groups, 2 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipEventCreate(&m->e0));
+    HIPCHK(ctx, hipEventCreate(&m->e1));
+    HIPCHK(ctx, hipEventCreate(&m->e2));
+    return DDDMR_OK;
+  };
+  int rc = init();
+  if (rc == DDDMR_OK) rc = marking_reset_locked(ctx);
+  if (rc != DDDMR_OK) { marking_free(m); ctx->marking = nullptr; }
+  return rc;
+}
+
+int dddmr_rollout_marking_reset(dddmr_rollout_ctx* ctx) {
+  if (!ctx) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  return marking_reset_locked(ctx);
+}
+
+}  // extern "C"
+
+namespace {
+// MultiLayerSpinningLidar::resetdGraph (:831-839): empty store, dGraph = max_obstacle_distance on keys 0..n_ground
+int marking_reset_locked(dddmr_rollout_ctx* ctx) {
+  MarkingState* m = ctx->marking;
+  if (!m) return fail(ctx, DDDMR_ERR_STATE, "marking_reset before marking_create");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  MarkStore& s = m->store;
+  const size_t t = m->table;
+  HIPCHK(ctx, hipMemsetAsync(s.keys, 0, t * sizeof(unsigned long long), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(s.alive, 0, t * sizeof(uint32_t), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(s.pts_ofs, 0, t * sizeof(uint32_t), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(s.pts_n, 0, t * sizeof(uint32_t), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(s.removed_seq, 0, t * sizeof(uint32_t), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(s.owner, 0, t * sizeof(unsigned long long), ctx->stream));
+  HIPCHK(ctx, hipMemsetAsync(s.lethal, 0, (size_t)m->n_ground + 1, ctx->stream));
+  hipLaunchKernelGGL(k_mk_fill_dgraph, dim3((m->n_ground + 1 + 255) / 256), dim3(256), 0, ctx->stream, m->n_ground + 1, s.dgraph,
+                     m->cfg.max_obstacle_distance);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  m->pool_used_host = 0;
+  // (pcl_msg_gbl_ is untouched by resetdGraph: the previous observation stays)
+  return DDDMR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sensor[7], const double T_gbl_base[7],
+                                 dddmr_marking_stats* stats) {
+  if (!ctx || !T_base_sensor || !T_gbl_base) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  MarkingState* m = ctx->marking;
+  if (!m) return fail(ctx, DDDMR_ERR_STATE, "marking_update before marking_create");
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "marking_update while a tick_begin is pending");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const dddmr_marking_config& c = m->cfg;
+  // the observation = the context's published aggregate cloud (global frame), pinned like a tick pins it
+  bool pending;
+  const int cidx = pin_front(ctx, &pending);
+  struct Release { dddmr_rollout_ctx* c; ~Release() { release_cloud(c); } } release{ctx};
+  if (pending) {
+    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->cloud_ready[cidx], 0));
+    cloud_wait_done(ctx, cidx);
+  }
+  const uint32_t n_obs = ctx->cloud_n[cidx];
+  const float4* obs = ctx->cloud_dev[cidx];
+
+  // ---- transforms (host, double): trans_gbl2s_af3_ = gbl2b * b2s (:236-237), its tf2 form (:238) ----
+  MarkParams k{};
+  double Rb[9], Rbs[9], Rs_e[9], ts[3];
+  quat_to_rot(T_gbl_base, Rb);
+  quat_to_rot(T_base_sensor, Rbs);
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) Rs_e[3 * i + j] = Rb[3 * i + 0] * Rbs[0 + j] + Rb[3 * i + 1] * Rbs[3 + j] + Rb[3 * i + 2] * Rbs[6 + j];
+    ts[i] = Rb[3 * i + 0] * T_base_sensor[0] + Rb[3 * i + 1] * T_base_sensor[1] + Rb[3 * i + 2] * T_base_sensor[2] + T_gbl_base[i];
+  }
+  double qs[4];
+  rot_to_quat(Rs_e, qs);
+  tf2_set_rotation(qs, k.Rs);
+  quat_rotate_z(qs, k.sn);
+  for (int i = 0; i < 3; ++i) k.st[i] = ts[i];
+  k.sd = -ts[0] * k.sn[0] - ts[1] * k.sn[1] - ts[2] * k.sn[2];
+  {
+    const double qb[4] = {T_gbl_base[3], T_gbl_base[4], T_gbl_base[5], T_gbl_base[6]};
+    double nb[3];
+    quat_rotate_z(qb, nb);
+    k.mc[0] = (float)nb[0]; k.mc[1] = (float)nb[1]; k.mc[2] = (float)nb[2];
+    const double d = -T_gbl_base[0] * nb[0] - T_gbl_base[1] * nb[1] - T_gbl_base[2] * nb[2];
+    k.mc[3] = (float)d;
+  }
+  k.res = c.xy_resolution; k.hres = c.height_resolution; k.marking_height = c.marking_height; k.window = c.perception_window_size;
+  k.fov_top = c.vertical_FOV_top; k.fov_bottom = c.vertical_FOV_bottom;
+  k.ps = c.scan_effective_positive_start; k.pe = c.scan_effective_positive_end;
+  k.ns = c.scan_effective_negative_start; k.ne = c.scan_effective_negative_end;
+  k.ignore_ratio = c.segmentation_ignore_ratio; k.inscribed = c.inscribed_radius; k.inflation = c.inflation_radius;
+  k.tol = (float)c.euclidean_cluster_extraction_tolerance;
+  k.tol2 = static_cast<float>(c.euclidean_cluster_extraction_tolerance * c.euclidean_cluster_extraction_tolerance);
+  k.min_cluster = c.euclidean_cluster_extraction_min_cluster_size;
+  k.wx0 = (int)((T_gbl_base[0] - c.perception_window_size) / c.xy_resolution);      // :489-496
+  k.wx1 = (int)((T_gbl_base[0] + c.perception_window_size) / c.xy_resolution);
+  k.wy0 = (int)((T_gbl_base[1] - c.perception_window_size) / c.xy_resolution);
+  k.wy1 = (int)((T_gbl_base[1] + c.perception_window_size) / c.xy_resolution);
+  k.wz0 = (int)((T_gbl_base[2] - c.marking_height) / c.height_resolution);
+  k.wz1 = (int)((T_gbl_base[2] + c.marking_height) / c.height_resolution);
+  k.n_obs = n_obs;
+  k.n_prev = m->prev >= 0 ? m->n_prev : 0;
+  k.table_mask = m->table - 1;
+  k.pool_cap = m->pool_cap;
+  k.n_ground = m->n_ground;
+  k.seq = ++m->seq;
+  if (k.seq == 0) k.seq = m->seq = 1;
+
+  MarkStore& s = m->store;
+  MarkCounters zero{};
+  zero.pool_used = m->pool_used_host;
+  HIPCHK(ctx, hipMemcpyAsync(m->counters, &zero, sizeof(zero), hipMemcpyHostToDevice, st));   // (pageable source: copied before return)
+  HIPCHK(ctx, hipEventRecord(m->e0, st));
+
+  // ---- pool compaction when half of it is garbage-or-used ----
+  if (m->pool_used_host > m->pool_cap / 2) {
+    hipLaunchKernelGGL(k_mk_compact_sizes, dim3((m->table + 255) / 256), dim3(256), 0, st, m->table, s, m->compact_sizes);
+    size_t tb = m->temp_bytes;
+    HIPCHK(ctx, rocprim::exclusive_scan(m->temp, tb, m->compact_sizes, m->compact_ofs, 0u, (size_t)m->table, rocprim::plus<uint32_t>(), st));
+    HIPCHK(ctx, hipMemsetAsync(&m->counters->pool_used, 0, sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_mk_compact_move, dim3((m->table + 3) / 4), dim3(256), 0, st, m->table, s, m->compact_ofs, m->pool_alt, m->counters);
+    std::swap(s.pool, m->pool_alt);
+  }
+
+  // ---- selfClear against the previous observation ----
+  const PointGrid empty_grid = m->obs[0].g;
+  const PointGrid& prev_grid = m->prev >= 0 ? m->obs[m->prev].g : empty_grid;
+  hipLaunchKernelGGL(k_mk_clear, dim3((m->table + 3) / 4), dim3(256), 0, st, k, s, prev_grid, m->counters);
+  hipLaunchKernelGGL(k_mk_unmark, dim3((m->table + 3) / 4), dim3(256), 0, st, k, s, m->ground.g);
+  HIPCHK(ctx, hipEventRecord(m->e1, st));
+
+  // ---- selfMark of this observation ----
+  if (n_obs > 5) {                                                               // :320-321
+    const int cur = m->prev >= 0 ? 1 - m->prev : 0;
+    GridBuf& gb = m->obs[cur];
+    // grid over the crop box of the feed (base frame |x|,|y| <= window, z in [0, marking_height]) in the global frame
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) { lo[a] = 3.4e38f; hi[a] = -3.4e38f; }
+    for (int corner = 0; corner < 8; ++corner) {
+      const double bx = (corner & 1) ? c.perception_window_size : -c.perception_window_size;
+      const double by = (corner & 2) ? c.perception_window_size : -c.perception_window_size;
+      const double bz = (corner & 4) ? c.marking_height : 0.0;
+      for (int a = 0; a < 3; ++a) {
+        const float v = (float)(Rb[3 * a] * bx + Rb[3 * a + 1] * by + Rb[3 * a + 2] * bz + T_gbl_base[a]);
+        lo[a] = std::min(lo[a], v - 0.3f);
+        hi[a] = std::max(hi[a], v + 0.3f);
+      }
+    }
+    const float cell = std::max(0.1f, k.tol);
+    grid_shape(gb.g, lo, hi, cell, cell, gb.cap_cells);
+    HIPCHK(ctx, hipMemcpyAsync(m->obs_copy[cur], obs, (size_t)n_obs * sizeof(float4), hipMemcpyDeviceToDevice, st));
+    const float4* pts = m->obs_copy[cur];
+    int rc = grid_build(ctx, m, gb, pts, n_obs, m->gslot, st);
+    if (rc != DDDMR_OK) return rc;
+    const dim3 pb((n_obs + 255) / 256), cb((n_obs + 63) / 64);
+    // Euclidean clusters
+    hipLaunchKernelGGL(k_mk_cc_init, pb, dim3(256), 0, st, n_obs, m->parent);
+    hipLaunchKernelGGL(k_mk_cc_union, pb, dim3(256), 0, st, k, gb.g, pts, m->parent);
+    hipLaunchKernelGGL(k_mk_cc_keys, pb, dim3(256), 0, st, n_obs, m->parent, m->keys_a);
+    size_t tb = m->temp_bytes;
+    HIPCHK(ctx, rocprim::radix_sort_keys(m->temp, tb, m->keys_a, m->keys1, (size_t)n_obs, 0, 40, st));
+    hipLaunchKernelGGL(k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys1, 20, m->flags);
+    tb = m->temp_bytes;
+    HIPCHK(ctx, rocprim::inclusive_scan(m->temp, tb, m->flags, m->cid_incl, (size_t)n_obs, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(k_mk_cluster_starts, pb, dim3(256), 0, st, n_obs, m->flags, m->cid_incl, m->cl, m->counters);
+    hipLaunchKernelGGL(k_mk_cluster_stage1, cb, dim3(64), 0, st, k, m->counters, m->cl, m->keys1, pts, m->ground.g);
+    // 0.2 m VoxelGrid of every surviving cluster: stable sort by (cluster, voxel), one lane per voxel
+    const int ox2 = (int)std::floor(lo[0] / 0.2f) - 16, oy2 = (int)std::floor(lo[1] / 0.2f) - 16, oz2 = (int)std::floor(lo[2] / 0.2f) - 16;
+    hipLaunchKernelGGL(k_mk_ds_keys, pb, dim3(256), 0, st, k, m->keys1, m->cid_incl, m->cl, pts, ox2, oy2, oz2, m->keys_a, m->vals_a);
+    tb = m->temp_bytes;
+    HIPCHK(ctx, rocprim::radix_sort_pairs(m->temp, tb, m->keys_a, m->keys_b, m->vals_a, m->vals_b, (size_t)n_obs, 0, 62, st));
+    hipLaunchKernelGGL(k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys_b, 0, m->flags);
+    tb = m->temp_bytes;
+    HIPCHK(ctx, rocprim::inclusive_scan(m->temp, tb, m->flags, m->incl, (size_t)n_obs, rocprim::plus<uint32_t>(), st));
+    HIPCHK(ctx, hipMemsetAsync(m->ds_first, 0xFF, (size_t)n_obs * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_mk_group_reduce, cb, dim3(64), 0, st, n_obs, m->keys_b, m->vals_b, m->flags, m->incl, 0, m->keys1, pts, m->ds,
+                       m->cl.ds_count, m->ds_first, m->n_groups);
+    hipLaunchKernelGGL(k_mk_cluster_stage2, cb, dim3(64), 0, st, k, m->counters, m->cl, m->map.g, m->n_map);
+    // projection on the base plane + 0.1 m VoxelGrid of the accepted clusters -> generator points
+    const int ox3 = (int)std::floor(lo[0] / 0.1f) - 64, oy3 = (int)std::floor(lo[1] / 0.1f) - 64, oz3 = (int)std::floor(lo[2] / 0.1f) - 64;
+    hipLaunchKernelGGL(k_mk_proj_keys, pb, dim3(256), 0, st, k, m->n_groups, m->ds, m->cl, ox3, oy3, oz3, m->proj, m->keys_a, m->vals_a, n_obs);
+    tb = m->temp_bytes;
+    HIPCHK(ctx, rocprim::radix_sort_pairs(m->temp, tb, m->keys_a, m->keys_b, m->vals_a, m->vals_b, (size_t)n_obs, 0, 62, st));
+    hipLaunchKernelGGL(k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys_b, 0, m->flags);
+    tb = m->temp_bytes;
+    HIPCHK(ctx, rocprim::inclusive_scan(m->temp, tb, m->flags, m->incl, (size_t)n_obs, rocprim::plus<uint32_t>(), st));
+    hipLaunchKernelGGL(k_mk_group_reduce, cb, dim3(64), 0, st, n_obs, m->keys_b, m->vals_b, m->flags, m->incl, 1, m->keys1, m->proj, m->gen,
+                       m->cl.gen_count, m->cl.gen_first, m->n_groups + 1);
+    // addPCPtr
+    hipLaunchKernelGGL(k_mk_slots, cb, dim3(64), 0, st, k, m->counters, m->cl, s, m->counters);
+    hipLaunchKernelGGL(k_mk_commit, cb, dim3(64), 0, st, k, m->counters, m->cl, s, m->counters, m->pool_ofs);
+    hipLaunchKernelGGL(k_mk_dgraph, cb, dim3(64), 0, st, k, m->n_groups + 1, m->gen, m->cl, m->pool_ofs, s, m->ground.g);
+    m->prev = cur;                                                               // pcl_msg_gbl_ of this selfMark
+    m->n_prev = n_obs;
+  }
+  hipLaunchKernelGGL(k_mk_finish, dim3((m->table + 255) / 256), dim3(256), 0, st, k, s, m->counters);
+  HIPCHK(ctx, hipEventRecord(m->e2, st));
+  MarkCounters out{};
+  HIPCHK(ctx, hipMemcpyAsync(&out, m->counters, sizeof(out), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  HIPCHK(ctx, hipGetLastError());
+  m->pool_used_host = out.pool_used;
+  if (stats) {
+    stats->n_observation = n_obs > 5 ? n_obs : 0;
+    stats->n_clusters = out.n_clusters_kept;
+    stats->n_marked = out.n_marked;
+    stats->n_in_window = out.n_in_window;
+    stats->n_cleared = out.n_cleared;
+    stats->n_alive = out.n_alive;
+    HIPCHK(ctx, hipEventElapsedTime(&stats->clear_ms, m->e0, m->e1));
+    HIPCHK(ctx, hipEventElapsedTime(&stats->mark_ms, m->e1, m->e2));
+  }
+  if (out.overflow)
+    return fail(ctx, DDDMR_ERR_CAPACITY, "marking_update: capacity flag %u (1: max_markings, 2: max_cluster_points)", out.overflow);
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_marking_get_voxels(dddmr_rollout_ctx* ctx, int32_t* xyz_out, size_t capacity, size_t* n) {
+  if (!ctx || !n) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  MarkingState* m = ctx->marking;
+  if (!m) return fail(ctx, DDDMR_ERR_STATE, "marking_get_voxels before marking_create");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<unsigned long long> keys(m->table);
+  std::vector<uint32_t> alive(m->table);
+  HIPCHK(ctx, hipMemcpy(keys.data(), m->store.keys, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(alive.data(), m->store.alive, alive.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  size_t cnt = 0;
+  for (size_t i = 0; i < keys.size(); ++i) {
+    if (!alive[i] || !keys[i]) continue;
+    if (xyz_out) {
+      if (cnt >= capacity) return fail(ctx, DDDMR_ERR_CAPACITY, "marking_get_voxels: capacity %zu too small", capacity);
+      int x, y, z;
+      voxel_unkey(keys[i], &x, &y, &z);
+      xyz_out[3 * cnt] = x; xyz_out[3 * cnt + 1] = y; xyz_out[3 * cnt + 2] = z;
+    }
+    ++cnt;
+  }
+  *n = cnt;
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_marking_get_dgraph(dddmr_rollout_ctx* ctx, double* values_out, size_t capacity) {
+  if (!ctx || !values_out) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  MarkingState* m = ctx->marking;
+  if (!m) return fail(ctx, DDDMR_ERR_STATE, "marking_get_dgraph before marking_create");
+  if (capacity < (size_t)m->n_ground + 1) return fail(ctx, DDDMR_ERR_CAPACITY, "marking_get_dgraph: capacity %zu < %u", capacity, m->n_ground + 1);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpy(values_out, m->store.dgraph, ((size_t)m->n_ground + 1) * sizeof(double), hipMemcpyDeviceToHost));
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_marking_get_lethal(dddmr_rollout_ctx* ctx, uint8_t* flags_out, size_t capacity) {
+  if (!ctx || !flags_out) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  MarkingState* m = ctx->marking;
+  if (!m) return fail(ctx, DDDMR_ERR_STATE, "marking_get_lethal before marking_create");
+  if (capacity < (size_t)m->n_ground + 1) return fail(ctx, DDDMR_ERR_CAPACITY, "marking_get_lethal: capacity %zu < %u", capacity, m->n_ground + 1);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipMemcpy(flags_out, m->store.lethal, (size_t)m->n_ground + 1, hipMemcpyDeviceToHost));
+  return DDDMR_OK;
+}
+
+}  // extern "C"

@@ -151,6 +151,9 @@ float absmax(const std::vector<float>& v) {
   return m;
 }
 
+struct MarkingState;                       // global-mode marking / clearing layer, marking_host.hip.h
+void marking_free(MarkingState* m);
+
 }  // namespace
 
 struct dddmr_rollout_ctx {
@@ -227,6 +230,8 @@ struct dddmr_rollout_ctx {
   int64_t* slots_dev = nullptr;      // [2 * comm_ranks] send: own slot written by k_score, INT64_MAX elsewhere
   int64_t* slots_red = nullptr;      // [2 * comm_ranks] receive
   DevResult* local_result_dev = nullptr;
+
+  MarkingState* marking = nullptr;   // dddmr_rollout_marking_create
 
   std::mutex tick_mu;
   std::mutex err_mu;        // last_error is written by tick and sensor threads alike
@@ -397,6 +402,8 @@ size_t dddmr_rollout_sizeof(int which) {
     case 3: return sizeof(dddmr_tick_input);
     case 4: return sizeof(dddmr_rollout_result);
     case 5: return sizeof(dddmr_rollout_debug);
+    case 6: return sizeof(dddmr_marking_config);
+    case 7: return sizeof(dddmr_marking_stats);
     default: return 0;
   }
 }
@@ -424,6 +431,7 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+  if (ctx->marking) { marking_free(ctx->marking); ctx->marking = nullptr; }
   if (ctx->comm) (void)rccl().comm_destroy(ctx->comm);
   if (ctx->slots_dev) (void)hipFree(ctx->slots_dev);
   if (ctx->slots_red) (void)hipFree(ctx->slots_red);
@@ -1502,3 +1510,5 @@ int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out, size
 }
 
 }  // extern "C"
+
+#include "marking_host.hip.h"

@@ -170,3 +170,88 @@ def feed(scan_xyz: np.ndarray, T_base_sensor, T_gbl_base, window: float, height:
     stride = scan.strides[0] if len(scan) else 12
     lib.oracle_feed(_ptr(scan), len(scan), stride, tbs, tgb, window, height, _ptr(out), len(out), C.byref(n))
     return out[: n.value].copy()
+
+
+class MarkingOracle:
+    """CPU restatement of the global-mode marking / clearing layer (oracle_marking.cpp)."""
+
+    def __init__(self, cfg: K.MarkingConfig, ground: np.ndarray, static_map: np.ndarray):
+        lib = load()
+        lib.oracle_marking_create.argtypes = [C.POINTER(K.MarkingConfig), C.c_void_p, C.c_size_t, C.c_size_t,
+                                              C.c_void_p, C.c_size_t, C.c_size_t]
+        lib.oracle_marking_create.restype = C.c_void_p
+        lib.oracle_marking_destroy.argtypes = [C.c_void_p]
+        lib.oracle_marking_reset.argtypes = [C.c_void_p]
+        lib.oracle_marking_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double),
+                                              C.POINTER(C.c_double), C.POINTER(K.MarkingStats)]
+        lib.oracle_marking_update.restype = C.c_int
+        for f in (lib.oracle_marking_get_voxels, lib.oracle_marking_get_dgraph, lib.oracle_marking_get_lethal):
+            f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+            f.restype = C.c_size_t
+        lib.oracle_marking_get_decisions.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.oracle_marking_get_decisions.restype = C.c_size_t
+        self._lib = lib
+        g = np.ascontiguousarray(ground, dtype=np.float32)
+        m = np.ascontiguousarray(static_map, dtype=np.float32)
+        if m.ndim != 2:
+            m = m.reshape(-1, 3)
+        self.n_ground = len(g)
+        self._h = lib.oracle_marking_create(C.byref(cfg), _ptr(g), len(g), g.strides[0] if len(g) else 12,
+                                            _ptr(m), len(m), m.strides[0] if len(m) else 12)
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.oracle_marking_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def reset(self):
+        self._lib.oracle_marking_reset(self._h)
+
+    def update(self, obs_gbl_xyz: np.ndarray, T_base_sensor, T_gbl_base) -> K.MarkingStats:
+        obs = np.ascontiguousarray(np.asarray(obs_gbl_xyz, dtype=np.float32)[:, :3])
+        tbs = (C.c_double * 7)(*[float(v) for v in T_base_sensor])
+        tgb = (C.c_double * 7)(*[float(v) for v in T_gbl_base])
+        st = K.MarkingStats()
+        self._lib.oracle_marking_update(self._h, _ptr(obs), len(obs), tbs, tgb, C.byref(st))
+        return st
+
+    def voxels(self) -> np.ndarray:
+        n = self._lib.oracle_marking_get_voxels(self._h, None, 0)
+        out = np.zeros((max(n, 1), 3), dtype=np.int32)
+        self._lib.oracle_marking_get_voxels(self._h, _ptr(out), len(out))
+        return out[:n]
+
+    def dgraph(self) -> np.ndarray:
+        out = np.zeros(self.n_ground + 1, dtype=np.float64)
+        self._lib.oracle_marking_get_dgraph(self._h, _ptr(out), out.size)
+        return out
+
+    def lethal(self) -> np.ndarray:
+        out = np.zeros(self.n_ground + 1, dtype=np.uint8)
+        self._lib.oracle_marking_get_lethal(self._h, _ptr(out), out.size)
+        return out.astype(bool)
+
+    def decisions(self, which: int):
+        """which = 0: selfClear (voxels, margins, removed); 1: selfMark (voxels, margins, added)."""
+        n = self._lib.oracle_marking_get_decisions(self._h, which, None, None, None, 0)
+        v = np.zeros((max(n, 1), 3), dtype=np.int32)
+        m = np.zeros(max(n, 1), dtype=np.float32)
+        f = np.zeros(max(n, 1), dtype=np.uint8)
+        self._lib.oracle_marking_get_decisions(self._h, which, _ptr(v), _ptr(m), _ptr(f), n)
+        return v[:n], m[:n], f[:n].astype(bool)
+
+
+def in_lidar_observation(cfg: K.MarkingConfig, T_base_sensor, T_gbl_base, pts_xyz: np.ndarray):
+    lib = load()
+    lib.oracle_in_lidar_observation.argtypes = [C.POINTER(K.MarkingConfig), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                                C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    pts = np.ascontiguousarray(pts_xyz, dtype=np.float32).reshape(-1, 3)
+    inside = np.zeros(len(pts), dtype=np.uint8)
+    margin = np.zeros(len(pts), dtype=np.float32)
+    tbs = (C.c_double * 7)(*[float(v) for v in T_base_sensor])
+    tgb = (C.c_double * 7)(*[float(v) for v in T_gbl_base])
+    lib.oracle_in_lidar_observation(C.byref(cfg), tbs, tgb, _ptr(pts), len(pts), _ptr(inside), _ptr(margin))
+    return inside.astype(bool), margin

@@ -31,7 +31,7 @@ def test_library_exports_every_header_symbol():
 def test_struct_layouts_match_compiled_library():
     lib = K.load_library()
     for i, t in enumerate([K.CriticConfig, K.TheoryConfig, K.RolloutConfig, K.TickInput,
-                           K.RolloutResult, K.RolloutDebug]):
+                           K.RolloutResult, K.RolloutDebug, K.MarkingConfig, K.MarkingStats]):
         assert C.sizeof(t) == lib.dddmr_rollout_sizeof(i), t.__name__
 
 

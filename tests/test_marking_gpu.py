@@ -1,0 +1,133 @@
+"""Global-mode marking / clearing layer: the HIP path through the C-ABI
+(dddmr_rollout_marking_*) against the CPU restatement (oracle/oracle_marking.cpp) of
+MultiLayerSpinningLidar::selfClear / selfMark + Marking::addPCPtr / removePCPtr, update by update over
+scan sequences of the C2 scene: the set of stored voxels, the dGraph, the lethal set and the per-update
+counts must be IDENTICAL (integer / set work bit-exact; dGraph distances are floats formed by the same
+operations in the same order, so they are compared exactly too).
+
+Both sides get the same observation (the cloud the device feed produced, in its order): the summation
+order of a cluster's centroid is the point order of pcl_msg_gbl_, an upstream artefact."""
+import math
+
+import numpy as np
+import pytest
+
+from dddmr_navigation_amd import _capi as K, marking, scenes
+from dddmr_navigation_amd.local_planner import LocalPlanner, RolloutError
+import oracle
+
+pytestmark = pytest.mark.gpu
+T_BS = (0.0, 0.0, 0.5, 0, 0, 0, 1)
+
+
+def _scene():
+    sc = scenes.bench_scene("C2")
+    cloud = sc.cloud
+    walls = cloud[(np.abs(np.abs(cloud[:, 1]) - 9.9) < 0.05)]
+    corridor = cloud[(np.abs(np.abs(cloud[:, 1]) - 4.5) < 0.05)]
+    return sc, cloud, walls, corridor
+
+
+def _vset(v):
+    return set(map(tuple, np.asarray(v).tolist()))
+
+
+def _run_sequence(cfg, static_map, poses, scene_of, window=5.0, height=2.0, ground=None, n_updates=10):
+    sc, cloud, _, _ = _scene()
+    ground = marking.ground_lattice() if ground is None else ground
+    mo = oracle.MarkingOracle(cfg, ground, static_map[:, :3])
+    totals = dict(marked=0, cleared=0, clusters=0)
+    with LocalPlanner([sc.theory], max_points=1 << 16) as lp:
+        layer = marking.MarkingLayer(lp, cfg, ground, static_map[:, :3])
+        for k in range(n_updates):
+            t_gb = poses(k)
+            scan = scenes.lidar_scan(scene_of(k, cloud), sensor_xyz=(t_gb[0], t_gb[1], t_gb[2] + 0.5), seed=100 + k)
+            lp.set_scan(scan, T_BS, t_gb, window, height)
+            obs = lp.get_cloud()
+            st = layer.update(T_BS, t_gb)
+            so = mo.update(obs[:, :3], T_BS, t_gb)
+            got = (st.n_observation, st.n_clusters, st.n_marked, st.n_in_window, st.n_cleared, st.n_alive)
+            want = (so.n_observation, so.n_clusters, so.n_marked, so.n_in_window, so.n_cleared, so.n_alive)
+            gv, ov = _vset(layer.voxels()), _vset(mo.voxels())
+            if gv != ov or got != want:
+                cv, cm, cf = mo.decisions(0)
+                mv, mm, mf = mo.decisions(1)
+                marg = {tuple(v): float(m) for v, m in zip(cv.tolist(), cm)}
+                marg.update({tuple(v): min(float(m), marg.get(tuple(v), 1e9)) for v, m in zip(mv.tolist(), mm)})
+                diff = sorted(gv ^ ov)
+                pytest.fail(f"update {k}: counts {got} vs oracle {want}; {len(diff)} voxels differ, "
+                            f"oracle margins of the first: {[(d, marg.get(d)) for d in diff[:6]]}")
+            np.testing.assert_array_equal(layer.lethal(), mo.lethal())
+            np.testing.assert_array_equal(layer.dgraph(), mo.dgraph())
+            totals["marked"] += so.n_marked; totals["cleared"] += so.n_cleared; totals["clusters"] += so.n_clusters
+        final = (len(gv), int((mo.dgraph() < cfg.max_obstacle_distance).sum()), int(mo.lethal().sum()))
+        layer.reset()
+        assert len(layer.voxels()) == 0 and (layer.dgraph() == cfg.max_obstacle_distance).all() and not layer.lethal().any()
+    return totals, final
+
+
+def test_shipped_config_ten_scans_with_a_vanishing_obstacle():
+    """The shipped global lidar block (tolerance 0.1, resolution 0.05, static check off): the robot drives
+    3 m down the corridor; from scan 5 on everything within 1.5 m of (2.5, 0) is gone, so the rays that used
+    to stop there pass and selfClear removes those markings."""
+    _, _, walls, _ = _scene()
+    cfg = marking.shipped_config()
+    poses = lambda k: (0.3 * k, 0.0, 0.0, 0, 0, 0, 1)
+    scene_of = lambda k, cloud: cloud if k < 5 else cloud[np.hypot(cloud[:, 0] - 2.5, cloud[:, 1]) > 1.5]
+    totals, final = _run_sequence(cfg, walls, poses, scene_of)
+    assert totals["marked"] > 5000 and totals["cleared"] > 3000 and final[0] > 1000 and final[2] > 100
+
+
+def test_coarse_clusters_static_map_and_tilted_robot():
+    """Tolerance 0.25 / min cluster size 3 (large wall clusters -> long summation chains), static-map
+    rejection on (segmentation_ignore_ratio 0.5, the corridor walls are the static map), robot pitched and
+    rolled by a few degrees and yawing (the projection plane and the FOV test follow base_link)."""
+    _, _, walls, corridor = _scene()
+    cfg = marking.shipped_config(euclidean_cluster_extraction_tolerance=0.25, euclidean_cluster_extraction_min_cluster_size=3,
+                                 segmentation_ignore_ratio=0.5, xy_resolution=0.1, height_resolution=0.1,
+                                 inscribed_radius=0.35, inflation_radius=1.0)
+    static_map = np.concatenate([walls, corridor])
+
+    def poses(k):
+        q = scenes.quat_from_rpy(0.03 * math.sin(k), 0.04 * math.cos(k), 0.0)     # (the synthetic scan keeps global axes: yaw 0)
+        return (0.25 * k, 0.1 * math.sin(k), 0.02 * k) + q
+    scene_of = lambda k, cloud: cloud if k % 4 else cloud[np.hypot(cloud[:, 0] - 3.0, cloud[:, 1] + 1.0) > 1.2]
+    totals, final = _run_sequence(cfg, static_map, poses, scene_of, n_updates=8)
+    assert totals["marked"] > 100 and totals["cleared"] > 10
+
+
+def test_small_observation_is_not_marked_and_counts_as_clear():
+    """<= 5 points: selfMark returns before touching pcl_msg_gbl_ (:320-321)."""
+    _, cloud, walls, _ = _scene()
+    cfg = marking.shipped_config()
+    ground = marking.ground_lattice()
+    mo = oracle.MarkingOracle(cfg, ground, walls[:, :3])
+    sc = scenes.bench_scene("C2")
+    with LocalPlanner([sc.theory], max_points=1 << 16) as lp:
+        layer = marking.MarkingLayer(lp, cfg, ground, walls[:, :3])
+        t_gb = (0.0, 0.0, 0.0, 0, 0, 0, 1)
+        tiny = np.array([[2.0, 0.1 * i, 0.5, 0] for i in range(4)], dtype=np.float32)
+        full = scenes.lidar_scan(cloud, sensor_xyz=(0, 0, 0.5), seed=5)
+        for obs_scan in (tiny, full, tiny, full):
+            lp.set_scan(obs_scan, T_BS, t_gb, 5.0, 2.0)
+            obs = lp.get_cloud()
+            st = layer.update(T_BS, t_gb)
+            so = mo.update(obs[:, :3], T_BS, t_gb)
+            assert (st.n_observation, st.n_clusters, st.n_marked, st.n_in_window, st.n_cleared, st.n_alive) == \
+                   (so.n_observation, so.n_clusters, so.n_marked, so.n_in_window, so.n_cleared, so.n_alive)
+            assert _vset(layer.voxels()) == _vset(mo.voxels())
+            np.testing.assert_array_equal(layer.dgraph(), mo.dgraph())
+
+
+def test_marking_capacity_and_state_errors():
+    sc = scenes.bench_scene("C1")
+    with LocalPlanner([sc.theory], max_points=1 << 14) as lp:
+        with pytest.raises(RolloutError) as e:
+            lp._check(lp._lib.dddmr_rollout_marking_update(lp._ctx, (7 * K.C.c_double)(), (7 * K.C.c_double)(), None))
+        assert e.value.code == K.ERR_STATE
+        _, cloud, walls, _ = _scene()
+        layer = marking.MarkingLayer(lp, marking.shipped_config(max_markings=64), marking.ground_lattice(), walls[:, :3])
+        lp.set_scan(scenes.lidar_scan(cloud, sensor_xyz=(0, 0, 0.5), seed=1), T_BS, (0, 0, 0, 0, 0, 0, 1), 5.0, 2.0)
+        with pytest.raises(RolloutError) as e:
+            layer.update(T_BS, (0, 0, 0, 0, 0, 0, 1))
+        assert e.value.code == K.ERR_CAPACITY

@@ -1,0 +1,105 @@
+"""CPU tests of the marking / clearing oracle (oracle/oracle_marking.cpp): answers derivable by hand
+from the reference source
+(/root/reference/src/dddmr_perception_3d/plugins/multilayer_spinning_lidar.cpp:306-746,
+plugins/cluster_marking.cpp:49-138).  PARITY UNPINNED: the reference holds no fixtures for this path."""
+import math
+
+import numpy as np
+
+from dddmr_navigation_amd import marking, scenes
+import oracle
+
+T_BS = (0.0, 0.0, 0.5, 0, 0, 0, 1)
+T_GB = (0.0, 0.0, 0.0, 0, 0, 0, 1)
+
+
+def test_fov_sector_and_elevation():
+    """isinLidarObservation (:682-746) with the shipped limits: elevation within +-15 deg of the sensor
+    plane, |yaw| in [30, 180] deg (the 60 deg sector ahead of the sensor is NOT effective)."""
+    cfg = marking.shipped_config()
+    z = 0.5                                             # sensor height: elevation 0
+    pts = np.array([[3.0, 3.0 * math.tan(math.radians(1.0)), z],       # yaw 1: inside the blind sector ahead
+                    [3.0, 3.0 * math.tan(math.radians(29.0)), z],      # yaw 29: still blind
+                    [3.0, 3.0 * math.tan(math.radians(31.0)), z],      # yaw 31: effective
+                    [0.0, 3.0, z], [-3.0, 0.1, z], [-3.0, -0.1, z],    # 90, ~178, ~-178
+                    [3.0, -3.0 * math.tan(math.radians(31.0)), z],     # yaw -31: effective
+                    [0.0, 3.0, z + 3.0 * math.tan(math.radians(14.0))],   # elevation 14: in
+                    [0.0, 3.0, z + 3.0 * math.tan(math.radians(16.0))],   # elevation 16: out
+                    [0.0, 3.0, z - 3.0 * math.tan(math.radians(16.0))]], dtype=np.float32)
+    inside, margin = oracle.in_lidar_observation(cfg, T_BS, T_GB, pts)
+    assert inside.tolist() == [False, False, True, True, True, True, True, True, False, False]
+    # the sector turns with the robot: yaw 90 deg puts the blind sector along +y
+    q = scenes.quat_from_rpy(0, 0, math.pi / 2)
+    inside, _ = oracle.in_lidar_observation(cfg, T_BS, (0, 0, 0) + q, pts[[0, 3]])
+    assert inside.tolist() == [True, False]
+    # quirk kept from the reference: a direction exactly along the global x axis makes the rotation axis
+    # (direction x (1,0,0)) the zero vector, the yaw NaN, and the function falls through to `return true`
+    inside, _ = oracle.in_lidar_observation(cfg, T_BS, T_GB, np.array([[3.0, 0.0, z], [-3.0, 0.0, z]], dtype=np.float32))
+    assert inside.tolist() == [True, True]
+
+
+def _blob(cx, cy, z0=0.2, z1=1.0):
+    zs = np.arange(z0, z1, 0.1)
+    return np.array([[cx + dx, cy + dy, z] for z in zs for dx in (-0.03, 0.03) for dy in (-0.03, 0.03)], dtype=np.float32)
+
+
+def test_mark_then_clear_one_cluster_by_hand():
+    """One compact obstacle at (0, 2) on a flat ground lattice: it becomes ONE cluster, its voxel key is
+    int(centroid / resolution), the dGraph of the ground nodes within inflation_radius drops to the xy
+    distance from the projected cluster, nodes within inscribed_radius become lethal; when the obstacle is
+    gone the ray through it passes and removePCPtr resets those nodes to 9999."""
+    cfg = marking.shipped_config(euclidean_cluster_extraction_tolerance=0.25)
+    ground = marking.ground_lattice(half=5.0, spacing=0.25, seed=1)
+    mo = oracle.MarkingOracle(cfg, ground, np.zeros((0, 3), np.float32))
+    far = _blob(-3.0, 3.0)                                   # keeps the observation above 5 points after the obstacle left
+    obs = np.concatenate([_blob(0.0, 2.0), far])
+    st = mo.update(obs, T_BS, T_GB)
+    assert (st.n_clusters, st.n_marked, st.n_in_window, st.n_cleared, st.n_alive) == (2, 2, 0, 0, 2)
+    vox = set(map(tuple, mo.voxels().tolist()))
+    c = _blob(0.0, 2.0).mean(0)
+    assert (int(c[0] / 0.05), int(c[1] / 0.05), int(c[2] / 0.05)) in vox
+    d = mo.dgraph()
+    assert len(d) == len(ground) + 1 and d[-1] == 9999.0           # DynamicGraph::initial fills n + 1 keys
+    gxy = ground[:, :2]
+    near = np.hypot(gxy[:, 0] - 0.0, gxy[:, 1] - 2.0)
+    touched = d[:-1] < 9999.0
+    assert touched[near < 1.3].all() and not touched[(near > 1.6) & (np.hypot(gxy[:, 0] + 3, gxy[:, 1] - 3) > 1.6)].any()
+    assert np.abs(d[:-1][near < 1.0] - near[near < 1.0]).max() < 0.06     # distance to the projected cluster (a 6 cm blob)
+    leth = mo.lethal()[:-1]
+    assert leth[near < 0.4].all() and not leth[(near > 0.6) & (np.hypot(gxy[:, 0] + 3, gxy[:, 1] - 3) > 0.6)].any()
+    # the obstacle at (0, 2) leaves: first update still clears against the OLD observation (ray blocked -> kept)
+    st = mo.update(far, T_BS, T_GB)
+    assert (st.n_in_window, st.n_cleared, st.n_alive) == (2, 0, 2)
+    # second update: pcl_msg_gbl_ now lacks it -> the ray passes, fewer than 2 points near the voxel -> removed
+    st = mo.update(far, T_BS, T_GB)
+    assert (st.n_in_window, st.n_cleared, st.n_alive) == (2, 1, 1)
+    d2 = mo.dgraph()[:-1]
+    assert (d2[near < 1.3] == 9999.0).all() and not mo.lethal()[:-1][near < 0.4].any()
+    assert (int(c[0] / 0.05), int(c[1] / 0.05), int(c[2] / 0.05)) not in set(map(tuple, mo.voxels().tolist()))
+
+
+def test_ground_attached_and_static_clusters_are_ignored():
+    ground = marking.ground_lattice(half=5.0, spacing=0.25, seed=1)
+    g0 = ground[np.argmin(np.hypot(ground[:, 0], ground[:, 1] - 2.0))]
+    flat = np.array([[g0[0] + dx, g0[1] + dy, g0[2]] for dx in (-0.02, 0.0, 0.02) for dy in (-0.02, 0.02)], dtype=np.float32)
+    other = _blob(-3.0, 3.0)
+    cfg = marking.shipped_config(euclidean_cluster_extraction_tolerance=0.25)
+    mo = oracle.MarkingOracle(cfg, ground, np.zeros((0, 3), np.float32))
+    st = mo.update(np.concatenate([flat, other]), T_BS, T_GB)
+    assert (st.n_clusters, st.n_marked) == (2, 1)            # centroid within 5 cm of a ground node (:364-368)
+    # static check (:375-389): a cluster whose centroid lies within 10 cm of the static map is dropped when
+    # segmentation_ignore_ratio < 1 ...
+    blob = _blob(0.0, 2.0)
+    static_map = blob.mean(0, keepdims=True).astype(np.float32)
+    for ratio, marked in ((0.5, 1), (1.1, 2)):               # ... and kept with the shipped 1.1 (the check is off)
+        mo = oracle.MarkingOracle(marking.shipped_config(euclidean_cluster_extraction_tolerance=0.25,
+                                                         segmentation_ignore_ratio=ratio), ground, static_map)
+        st = mo.update(np.concatenate([blob, other]), T_BS, T_GB)
+        assert (st.n_clusters, st.n_marked) == (2, marked)
+
+
+def test_small_observation_returns_early():
+    cfg = marking.shipped_config()
+    mo = oracle.MarkingOracle(cfg, marking.ground_lattice(half=3.0), np.zeros((0, 3), np.float32))
+    st = mo.update(_blob(0.0, 2.0)[:5], T_BS, T_GB)
+    assert (st.n_observation, st.n_clusters, st.n_marked, st.n_alive) == (0, 0, 0, 0)
