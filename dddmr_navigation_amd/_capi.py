@@ -178,6 +178,7 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_destroy",
     "dddmr_rollout_set_cloud",
     "dddmr_rollout_set_scan",
+    "dddmr_rollout_set_stitcher",
     "dddmr_rollout_get_cloud",
     "dddmr_rollout_set_prune_plan",
     "dddmr_rollout_tick",
@@ -239,6 +240,8 @@ def load_library() -> C.CDLL:
         ctx_p, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_double),
         C.c_double, C.c_double, C.POINTER(C.c_uint32)]
     lib.dddmr_rollout_set_scan.restype = C.c_int
+    lib.dddmr_rollout_set_stitcher.argtypes = [ctx_p, C.c_int32]
+    lib.dddmr_rollout_set_stitcher.restype = C.c_int
     lib.dddmr_rollout_get_cloud.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.dddmr_rollout_get_cloud.restype = C.c_int
     lib.dddmr_rollout_set_prune_plan.argtypes = [ctx_p, C.c_void_p, C.c_size_t]

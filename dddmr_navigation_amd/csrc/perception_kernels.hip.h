@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include <cstring>
+#include <deque>
 
 // The reference is an x86-64 build without FMA contraction: every multiply and add below
 // rounds separately, in float and in double (hipcc's default would fuse them).
@@ -48,6 +49,9 @@ struct PerceptionScratch {
   size_t cap_points = 0;
   size_t cap_slots = 0;
   uint32_t seq = 0;
+  // stitcher (cbSensor :185-200): the last stitcher_num raw scans, oldest first, packed xyz in `stage`
+  int stitcher_num = 0;
+  std::deque<uint32_t> stitched;       // point counts of the queued scans
 };
 
 // key 0 = empty slot (a real key always has bit 63 set)
@@ -181,17 +185,43 @@ inline void perception_free(PerceptionScratch& s) {
 }
 
 // scan: caller's records (stride_bytes apart, x y z first).  Output: out_dev (global frame).
+// With a stitcher depth N > 0 the scan joins the queue of the last N raw scans (the oldest one leaves when
+// the queue is full) and the WHOLE queue, oldest first, is fed through the current transforms -- cbSensor's
+// pcl_stitcher_ deque (multilayer_spinning_lidar.cpp:185-200).
 inline int perception_feed(PerceptionScratch& s, FeedParams f, const float* scan, size_t stride_bytes,
                            float4* out_dev, hipStream_t stream, uint32_t* n_out) {
   *n_out = 0;
+  int stride_floats;
+  if (s.stitcher_num > 0) {
+    if ((int)s.stitched.size() >= s.stitcher_num) {            // pop_front: the later scans move up
+      const size_t drop = s.stitched.front();
+      s.stitched.pop_front();
+      size_t rest = 0;
+      for (uint32_t c : s.stitched) rest += c;
+      std::memmove(s.stage, s.stage + 3 * drop, rest * 3 * sizeof(float));
+    }
+    size_t have = 0;
+    for (uint32_t c : s.stitched) have += c;
+    if (have + (size_t)f.n > s.cap_points) return -2;
+    const size_t sf = stride_bytes / 4;
+    for (size_t i = 0; i < (size_t)f.n; ++i) {
+      s.stage[3 * (have + i) + 0] = scan[i * sf + 0];
+      s.stage[3 * (have + i) + 1] = scan[i * sf + 1];
+      s.stage[3 * (have + i) + 2] = scan[i * sf + 2];
+    }
+    s.stitched.push_back((uint32_t)f.n);
+    f.n = (int)(have + (size_t)f.n);
+    stride_floats = 3;
+  }
   if (f.n == 0) return 0;
   size_t slots = 1024;
   while (slots < 2 * (size_t)f.n) slots <<= 1;
   if (slots > s.cap_slots) return -2;
   // stage the raw records in pinned memory: packed xyz(i) records go as they are,
   // wider ones (PCL: 16/32 bytes) are narrowed to 12 bytes on the way
-  int stride_floats;
-  if (stride_bytes == 12 || stride_bytes == 16) {
+  if (s.stitcher_num > 0) {
+    // (already staged above)
+  } else if (stride_bytes == 12 || stride_bytes == 16) {
     stride_floats = (int)(stride_bytes / 4);
     std::memcpy(s.stage, scan, (size_t)f.n * stride_bytes);
   } else {

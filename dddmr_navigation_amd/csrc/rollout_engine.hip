@@ -646,6 +646,7 @@ int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_po
     return fail(ctx, DDDMR_ERR_BAD_ARG, "set_scan: bad pointer/stride");
   if (n_points > ctx->cfg.max_points)
     return fail(ctx, DDDMR_ERR_CAPACITY, "set_scan: %zu points > max_points %u", n_points, ctx->cfg.max_points);
+  if (ctx->feed.stitcher_num > 0 && n_points == 0) return fail(ctx, DDDMR_ERR_BAD_ARG, "set_scan: empty scan with the stitcher on");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> prod(ctx->producer_mu);
   const int back = acquire_back(ctx);
@@ -661,11 +662,20 @@ int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_po
   fp.height = (float)marking_height;
   uint32_t n_out = 0;
   const int rc = perception_feed(ctx->feed, fp, xyz, stride_bytes, ctx->cloud_dev[back], ctx->copy_stream, &n_out);
+  if (rc == -2) return fail(ctx, DDDMR_ERR_CAPACITY, "set_scan: the (stitched) scan exceeds max_points %u", ctx->cfg.max_points);
   if (rc != 0) return fail(ctx, DDDMR_ERR_HIP, "set_scan: perception feed failed (%d)", rc);
   // the tick's stream waits on this event, so the feed kernels need not have retired yet
   HIPCHK(ctx, hipEventRecord(ctx->cloud_ready[back], ctx->copy_stream));
   publish_cloud(ctx, back, n_out);
   if (n_out_points) *n_out_points = n_out;
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_set_stitcher(dddmr_rollout_ctx* ctx, int32_t stitcher_num) {
+  if (!ctx || stitcher_num < 0) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> prod(ctx->producer_mu);
+  ctx->feed.stitcher_num = stitcher_num;
+  ctx->feed.stitched.clear();
   return DDDMR_OK;
 }
 

@@ -124,6 +124,10 @@ class LocalPlanner:
                                                      C.byref(n_out)))
         return int(n_out.value)
 
+    def set_stitcher(self, stitcher_num: int):
+        """cbSensor's `stitcher_num` (multilayer_spinning_lidar.cpp:185-200): feed the last N raw scans together."""
+        self._check(self._lib.dddmr_rollout_set_stitcher(self._ctx, int(stitcher_num)))
+
     def get_cloud(self) -> np.ndarray:
         n = C.c_size_t(0)
         self._check(self._lib.dddmr_rollout_get_cloud(self._ctx, None, 0, C.byref(n)))

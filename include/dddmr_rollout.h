@@ -231,6 +231,13 @@ int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_po
                            const double T_gbl_base[7], double perception_window_size,
                            double marking_height, uint32_t* n_out_points);
 
+/* cbSensor's stitcher (multilayer_spinning_lidar.cpp:185-200, parameter `stitcher_num`): with
+   stitcher_num > 0 every dddmr_rollout_set_scan feeds the last stitcher_num RAW scans, oldest first,
+   through the CURRENT transforms (exactly what the reference does: the queued scans are not
+   re-registered).  0 switches it off and empties the queue.  The queued scans together must fit
+   max_points. */
+int dddmr_rollout_set_stitcher(dddmr_rollout_ctx* ctx, int32_t stitcher_num);
+
 /* Copy the current aggregate observation back (debug / parity of set_scan). */
 int dddmr_rollout_get_cloud(dddmr_rollout_ctx* ctx, float* xyzi_out, size_t capacity,
                             size_t* n_points);

@@ -89,3 +89,27 @@ def test_set_scan_edge_cases():
             lp.set_scan(np.zeros((5000, 3), np.float32), ident, ident, 5.0, 2.0)
         assert e.value.code == K.ERR_CAPACITY
         assert lp.set_scan(wide, ident, ident, 5.0, 2.0) == 2
+
+
+def test_stitcher_feeds_the_last_n_raw_scans_through_the_current_transforms():
+    """cbSensor's pcl_stitcher_ deque (multilayer_spinning_lidar.cpp:185-200): with stitcher_num = 3 the
+    observation is the feed of the last three RAW scans concatenated, oldest first, all transformed with
+    the transforms of the newest callback."""
+    from scipy.spatial import cKDTree
+    cloud = scenes.cloud_c2()
+    scans = [scenes.lidar_scan(cloud, sensor_xyz=(0.2 * i, 0.0, 0.5), seed=20 + i)[:: 2 + i % 2] for i in range(5)]
+    tbs = (0.0, 0.0, 0.5, 0, 0, 0, 1)
+    th = configs.bench_theory("C2")
+    with LocalPlanner([th], max_points=60_000) as lp:
+        lp.set_stitcher(3)
+        for i, scan in enumerate(scans):
+            tgb = (0.2 * i, 0.0, 0.0) + scenes.quat_from_rpy(0.0, 0.0, 0.05 * i)
+            n = lp.set_scan(scan, tbs, tgb, 8.0, 1.8)
+            got = lp.get_cloud()[:, :3]
+            ref = oracle.feed(np.concatenate(scans[max(0, i - 2): i + 1]), tbs, tgb, 8.0, 1.8)
+            assert n == len(ref) == len(got)
+            d, idx = cKDTree(ref).query(got)
+            assert d.max() <= 1e-5 and len(np.unique(idx)) == len(ref)
+        lp.set_stitcher(0)                                   # off again: only the newest scan
+        n = lp.set_scan(scans[0], tbs, (0, 0, 0, 0, 0, 0, 1), 8.0, 1.8)
+        assert n == len(oracle.feed(scans[0], tbs, (0, 0, 0, 0, 0, 0, 1), 8.0, 1.8))
