@@ -181,6 +181,7 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_set_stitcher",
     "dddmr_rollout_get_cloud",
     "dddmr_rollout_set_prune_plan",
+    "dddmr_rollout_samples",
     "dddmr_rollout_tick",
     "dddmr_rollout_tick_begin",
     "dddmr_rollout_tick_end",
@@ -189,6 +190,7 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_resolve_words",
     "dddmr_rollout_get_debug",
     "dddmr_rollout_get_best_poses",
+    "dddmr_rollout_get_best_cuboids",
     "dddmr_rollout_get_pose_arrays",
     "dddmr_rollout_path_blocked",
     "dddmr_rollout_pack_key",
@@ -246,6 +248,8 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_get_cloud.restype = C.c_int
     lib.dddmr_rollout_set_prune_plan.argtypes = [ctx_p, C.c_void_p, C.c_size_t]
     lib.dddmr_rollout_set_prune_plan.restype = C.c_int
+    lib.dddmr_rollout_samples.argtypes = [ctx_p, C.c_char_p, C.POINTER(TickInput), C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.dddmr_rollout_samples.restype = C.c_int
     lib.dddmr_rollout_tick.argtypes = [ctx_p, C.c_char_p, C.POINTER(TickInput), C.POINTER(RolloutResult)]
     lib.dddmr_rollout_tick.restype = C.c_int
     lib.dddmr_rollout_tick_begin.argtypes = [ctx_p, C.c_char_p, C.POINTER(TickInput)]
@@ -262,6 +266,8 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_get_debug.restype = C.c_int
     lib.dddmr_rollout_get_best_poses.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.dddmr_rollout_get_best_poses.restype = C.c_int
+    lib.dddmr_rollout_get_best_cuboids.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.dddmr_rollout_get_best_cuboids.restype = C.c_int
     lib.dddmr_rollout_get_pose_arrays.argtypes = [ctx_p, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.dddmr_rollout_get_pose_arrays.restype = C.c_int
     lib.dddmr_rollout_path_blocked.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.c_double, C.POINTER(C.c_double),

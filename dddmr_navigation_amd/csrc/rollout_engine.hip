@@ -1422,6 +1422,23 @@ int dddmr_rollout_stream_ceiling(dddmr_rollout_ctx* ctx, size_t bytes, int32_t r
   return rc;
 }
 
+// The theory's initialise() alone: the velocity samples a tick with these inputs would roll out, in the
+// reference's generation order (x-major, y, theta-minor).  Host-only, no device work.
+int dddmr_rollout_samples(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_tick_input* in, float* samples_out,
+                          size_t capacity, size_t* n_samples) {
+  if (!ctx || !theory_name || !in || !n_samples) return DDDMR_ERR_BAD_ARG;
+  const dddmr_theory_config* th = find_theory(ctx, theory_name);
+  if (!th) return fail(ctx, DDDMR_ERR_UNKNOWN_THEORY, "unknown theory '%s'", theory_name);
+  Window w;
+  make_window(*th, *in, w);
+  const size_t n = w.count();
+  *n_samples = n;
+  if (!samples_out) return DDDMR_OK;
+  if (capacity < n) return fail(ctx, DDDMR_ERR_CAPACITY, "samples: capacity %zu < %zu", capacity, n);
+  for (size_t i = 0; i < n; ++i) sample_of(w, (int)i, samples_out + 3 * i, samples_out + 3 * i + 1, samples_out + 3 * i + 2);
+  return DDDMR_OK;
+}
+
 int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg) {
   if (!ctx || !dbg) return DDDMR_ERR_BAD_ARG;
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
@@ -1513,9 +1530,37 @@ int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out, size
   if (!poses_out) return DDDMR_OK;
   if (capacity < (size_t)ns) return fail(ctx, DDDMR_ERR_CAPACITY, "get_best_poses: capacity %zu < %d", capacity, ns);
   hipLaunchKernelGGL(k_trajectory_poses, dim3(1), dim3(64), 0, ctx->stream, ctx->last, li, ctx->samples_out,
-                     ctx->steps, ctx->poses_dev);
+                     ctx->steps, ctx->poses_dev, (float*)nullptr);
   HIPCHK(ctx, hipMemcpyAsync(poses_out, ctx->poses_dev, (size_t)ns * 7 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_get_best_cuboids(dddmr_rollout_ctx* ctx, float* vertices_out, size_t capacity_poses, size_t* n_poses) {
+  if (!ctx || !n_poses) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (!ctx->have_last) return fail(ctx, DDDMR_ERR_STATE, "get_best_cuboids before any tick");
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "get_best_cuboids while a tick_begin is pending");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  const int32_t idx = ctx->last_result.index;
+  *n_poses = 0;
+  if (idx < 0) return DDDMR_OK;
+  const int li = idx - ctx->last.begin;
+  if (li < 0 || li >= ctx->last.n_local) return DDDMR_OK;  // winner is on another rank
+  int32_t ns = 0;
+  HIPCHK(ctx, hipMemcpy(&ns, ctx->steps + li, sizeof(int32_t), hipMemcpyDeviceToHost));
+  *n_poses = (size_t)ns;
+  if (!vertices_out || ns == 0) return DDDMR_OK;
+  if (capacity_poses < (size_t)ns) return fail(ctx, DDDMR_ERR_CAPACITY, "get_best_cuboids: capacity %zu < %d", capacity_poses, ns);
+  float* cub_dev = nullptr;
+  HIPCHK(ctx, hipMalloc(&cub_dev, (size_t)ns * 24 * sizeof(float)));
+  hipLaunchKernelGGL(k_trajectory_poses, dim3(1), dim3(64), 0, ctx->stream, ctx->last, li, ctx->samples_out,
+                     ctx->steps, ctx->poses_dev, cub_dev);
+  const hipError_t e = hipMemcpyAsync(vertices_out, cub_dev, (size_t)ns * 24 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(cub_dev);
+  if (e != hipSuccess || e2 != hipSuccess) return fail(ctx, DDDMR_ERR_HIP, "get_best_cuboids: copy failed");
   return DDDMR_OK;
 }
 

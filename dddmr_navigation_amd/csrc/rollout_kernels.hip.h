@@ -1650,8 +1650,11 @@ __device__ __forceinline__ void write_pose(const double L[9], const double T[3],
 // Poses of one trajectory for visualisation (local_planner.cpp:472-478 publishes
 // the best trajectory): position + Quaterniond(T.linear()) per step, recomputed
 // by one lane with the same recurrence as k_score.
+// cub_out (may be null): the 8 cuboid vertices carried along every pose, [step][8][3] floats --
+// Trajectory::getCuboid(i) = pcl::transformPointCloud(cuboid, Affine3d) (dd_simple...cpp:443).
 __global__ void k_trajectory_poses(DevTick k, int li, const float4* __restrict__ samples_out,
-                                   const int32_t* __restrict__ steps, double* __restrict__ poses) {
+                                   const int32_t* __restrict__ steps, double* __restrict__ poses,
+                                   float* __restrict__ cub_out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const float4 smp = samples_out[li];
   const int ns = steps[li];
@@ -1683,6 +1686,14 @@ __global__ void k_trajectory_poses(DevTick k, int li, const float4* __restrict__
       T[i] = r0 * (double)px + r1 * (double)py + k.t[i];
     }
     write_pose(L, T, poses + 7 * (size_t)s);
+    if (cub_out) {
+      for (int v = 0; v < 8; ++v) {
+        const double cx = k.cub[3 * v + 0], cy = k.cub[3 * v + 1], cz = k.cub[3 * v + 2];
+        cub_out[(size_t)s * 24 + 3 * v + 0] = (float)(L[0] * cx + L[1] * cy + L[2] * cz + T[0]);
+        cub_out[(size_t)s * 24 + 3 * v + 1] = (float)(L[3] * cx + L[4] * cy + L[5] * cz + T[1]);
+        cub_out[(size_t)s * 24 + 3 * v + 2] = (float)(L[6] * cx + L[7] * cy + L[8] * cz + T[2]);
+      }
+    }
   }
 }
 

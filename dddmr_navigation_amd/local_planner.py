@@ -156,6 +156,15 @@ class LocalPlanner:
                                                          flags.ctypes.data_as(C.c_void_p)))
         return ratio.value, op.value, flags[: len(plan)].astype(bool)
 
+    def samples(self, traj_gen_name: str, tick_in: K.TickInput) -> np.ndarray:
+        """The theory's initialise(): the sample list a tick would roll out, [N,3] vx vy wz (host-only)."""
+        n = C.c_size_t(0)
+        self._check(self._lib.dddmr_rollout_samples(self._ctx, traj_gen_name.encode(), C.byref(tick_in), None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), dtype=np.float32)
+        self._check(self._lib.dddmr_rollout_samples(self._ctx, traj_gen_name.encode(), C.byref(tick_in),
+                                                    out.ctypes.data_as(C.c_void_p), out.shape[0], C.byref(n)))
+        return out[: n.value]
+
     # -- the tick ----------------------------------------------------------
     def tick(self, traj_gen_name: str, tick_in: K.TickInput) -> K.RolloutResult:
         res = K.RolloutResult()
@@ -259,4 +268,13 @@ class LocalPlanner:
         out = np.zeros((max(n.value, 1), 7), dtype=np.float64)
         self._check(self._lib.dddmr_rollout_get_best_poses(self._ctx, out.ctypes.data_as(C.c_void_p), out.shape[0],
                                                            C.byref(n)))
+        return out[: n.value]
+
+    def best_cuboids(self) -> np.ndarray:
+        """Cuboid vertices carried along the best trajectory, [n_poses, 8, 3] float32."""
+        n = C.c_size_t(0)
+        self._check(self._lib.dddmr_rollout_get_best_cuboids(self._ctx, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 8, 3), dtype=np.float32)
+        self._check(self._lib.dddmr_rollout_get_best_cuboids(self._ctx, out.ctypes.data_as(C.c_void_p), out.shape[0],
+                                                             C.byref(n)))
         return out[: n.value]

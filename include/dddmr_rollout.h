@@ -266,6 +266,14 @@ int dddmr_rollout_path_blocked(dddmr_rollout_ctx* ctx, const float* plan_xyzi, s
                                double check_radius, double* blocked_ratio_percent, int32_t* opinion,
                                uint8_t* blocked_flags);
 
+/* The theory's initialise() alone (dd_simple...cpp:236-295, omni_simple...cpp:260-332,
+   dd_rotate_inplace_theory.cpp:229-274): the velocity samples a tick with these inputs rolls out, in
+   generation order, samples_out[n][3] = vx vy wz.  Host-only (no device work); call with NULL for the
+   count.  An iterator-protocol adapter (hasMoreTrajectories / nextTrajectory) needs the list before the
+   batch has been scored. */
+int dddmr_rollout_samples(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_tick_input* in,
+                          float* samples_out, size_t capacity, size_t* n_samples);
+
 /* One control tick for the named theory. */
 int dddmr_rollout_tick(dddmr_rollout_ctx* ctx, const char* theory_name,
                        const dddmr_tick_input* in, dddmr_rollout_result* out);
@@ -335,6 +343,14 @@ int dddmr_rollout_get_pose_arrays(dddmr_rollout_ctx* ctx, int32_t which, double*
    (local_planner.cpp:472-478): poses_out[n][7] x y z qx qy qz qw. */
 int dddmr_rollout_get_best_poses(dddmr_rollout_ctx* ctx, double* poses_out,
                                  size_t capacity, size_t* n_poses);
+
+/* Cuboids of the best trajectory, vertices_out[n][8][3] floats in the vertex order of the theory's
+   cuboid: base_trajectory::Trajectory::getCuboid(i) of every pose (trajectory.cpp:52-54, filled at
+   dd_simple...cpp:443).  The reference collects them for a `trajectory_cuboids` debug cloud whose
+   publication is commented out (local_planner.cpp:118,454,572-573,631); its `robot_cuboid` topic is a
+   static marker built from the YAML vertices (:159-190,364-367) and needs no compute. */
+int dddmr_rollout_get_best_cuboids(dddmr_rollout_ctx* ctx, float* vertices_out, size_t capacity_poses,
+                                   size_t* n_poses);
 
 /* Argmin key: min over keys == minimum cost, ties -> highest index (the
    reference's `<=` scan keeps the LAST minimal trajectory,

@@ -288,6 +288,7 @@ def test_debug_pose_arrays_match_oracle(cfg):
         every = lp.pose_arrays()
         accepted = lp.pose_arrays(accepted_only=True)
         best = lp.best_poses()
+        best_cub = lp.best_cuboids()
     o = oracle.tick(th, cloud, plan, tick)
     want_all, want_acc = [], []
     for i in range(len(steps)):
@@ -306,6 +307,10 @@ def test_debug_pose_arrays_match_oracle(cfg):
     bi = o.result.best_index
     start = int(sum(steps[i] for i in range(bi) if costs[i] >= 0))
     np.testing.assert_allclose(accepted[start:start + steps[bi]], best, atol=1e-12)
+    # ... and its cuboids are Trajectory::getCuboid(i) of every pose (8 vertices, the theory's vertex order)
+    _, ref_cub, _ = oracle.generate(th, tick, o.samples[bi])
+    assert best_cub.shape == ref_cub.shape == (steps[bi], 8, 3)
+    np.testing.assert_allclose(best_cub, ref_cub, atol=2e-6)
 
 
 def test_tick_begin_end_equals_tick_and_guards_state():
@@ -549,3 +554,19 @@ def test_failed_tick_does_not_lose_the_upload_ordering():
             assert res.n_points_binned > 1000
             assert ((costs < 0) == (o.costs < 0)).mean() > 0.999     # (fragile points may flip a verdict)
             assert res.planner_state == o.result.planner_state
+
+
+def test_samples_entry_point_is_the_theorys_initialise():
+    """dddmr_rollout_samples (host-only) = the sample list the tick rolls out = the oracle's initialise()."""
+    sc = scenes.playground_scene()
+    omni = configs.omni_simple_shipped()
+    rot = configs.rotate_inplace_shipped("rot")
+    with LocalPlanner([sc.theory, omni, rot]) as lp:
+        for th, tick in ((sc.theory, sc.tick), (omni, scenes.tick_input(twist=(0.3, 0.1, 0.0))), (rot, scenes.tick_input())):
+            name = th.name.decode()
+            got = lp.samples(name, tick)
+            np.testing.assert_array_equal(got, oracle.samples(th, tick))
+            lp.set_cloud(sc.cloud)
+            lp.setPlan(sc.plan)
+            lp.tick(name, tick)
+            np.testing.assert_array_equal(lp.debug()[2], got)
