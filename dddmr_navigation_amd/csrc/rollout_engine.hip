@@ -192,6 +192,7 @@ struct dddmr_rollout_ctx {
   int load_theory = -1, load_nlocal = -1;   // what traj_load describes
   bool no_assign = false;
   bool no_boxfast = false;   // DDDMR_NO_BOXFAST: always take the general vertex transform
+  bool no_tab = false;       // DDDMR_NO_TAB: k_score reads the row-run index from L2 instead of staging it in LDS
   // DDDMR_POISON=1 (tests): fill the per-trajectory outputs with NaN / -1 patterns before every
   // tick, so a trajectory the scorer skipped cannot pass for scored with last tick's values
   bool poison = false;
@@ -249,6 +250,7 @@ struct dddmr_rollout_ctx {
   int timing = 1;   // DDDMR_TIMING: 0 no HIP events, 1 around k_score (score_ms), 2 also around the whole tick
   int timing_every = 1;   // DDDMR_TIMING_EVERY: record the events on every n-th tick only
   int spin = 1;     // DDDMR_SPIN: poll the host-mapped result instead of hipStreamSynchronize
+  int final_mode = -1;   // DDDMR_FINAL: 1 always decode in k_finalize, 0 always in k_score's last workgroup, -1 by shard size
   uint32_t seq = 0;
   DevResult last_result{};   // host copy of the last COLLECTED tick's result
   float last_score_ms = 0.f, last_device_ms = 0.f;
@@ -495,6 +497,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
   if (const char* e = std::getenv("DDDMR_TIMING")) ctx->timing = std::atoi(e);
   if (const char* e = std::getenv("DDDMR_TIMING_EVERY")) ctx->timing_every = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("DDDMR_SPIN")) ctx->spin = std::atoi(e);
+  if (const char* e = std::getenv("DDDMR_FINAL")) ctx->final_mode = std::atoi(e) ? 1 : 0;
 
   auto init = [&]() -> int {
     HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -534,6 +537,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMalloc(&ctx->assign, N * sizeof(uint32_t)));
     ctx->no_assign = std::getenv("DDDMR_NO_ASSIGN") != nullptr;
     ctx->no_boxfast = std::getenv("DDDMR_NO_BOXFAST") != nullptr;
+    ctx->no_tab = std::getenv("DDDMR_NO_TAB") != nullptr;
     ctx->poison = std::getenv("DDDMR_POISON") != nullptr;
     ctx->host_prof = std::getenv("DDDMR_HOST_PROF") != nullptr;
     ctx->gnz_one = std::getenv("DDDMR_GNZ_ONE") != nullptr;
@@ -965,7 +969,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   const int rec_words = rec_words_of(k.rec_pose != 0, k.want_minmax != 0);
   {
     const long te = (long)(k.gnx + 1) * k.gny;
-    k.tab_entries = (te <= kTabCap && k.n_points >= 5 && (k.want_collision || k.want_minmax)) ? (int)te : 0;
+    k.tab_entries = (te <= kTabCap && k.n_points >= 5 && (k.want_collision || k.want_minmax) && !ctx->no_tab) ? (int)te : 0;
   }
   // Workgroup shape.  Default: 256 lanes and the tile that keeps the most (trajectory, step)
   // slots resident per CU with the slots of one workgroup fitting its lanes (one pair per
@@ -976,35 +980,49 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   // per SIMD and <= 80 KB of LDS), that shape wins instead: the launch is bound by its
   // heaviest tile's collision walk and 512 lanes both halve it and average over more
   // trajectories (C2).
-  int thr = 256;
+  // Workgroup shape.  Per-workgroup fixed costs (staging the plan and the row-run index, ~13 barriers, the wave-0
+  // scans) make few, fat workgroups win: measured on the r02 scenes, k_score at C3 (80-step rows) 256 lanes x tile
+  // 2 / 3 / 4 -> 222 / 158 / 152 us, 512 lanes x tile 6 -> 132 us; C4 (50-step rows) 256 lanes x tile 3 / 5 / 7 ->
+  // 564 / 344 / 336 us, 512 lanes x tile 8 / 10 / 11 -> 347 / 304 / 320 us.  So: 512 lanes (two workgroups per CU
+  // at 4 waves per SIMD and <= 80 KB of LDS each) and
+  //  - a shard that fits ONE round of resident workgroups is spread evenly over them (C2: tile 8, 512 workgroups);
+  //  - a bigger shard takes the largest tile whose (trajectory, step) pairs still fit the lanes (one pair per lane
+  //    in D1 / D2) and whose LDS fits twice into a CU.
+  // DDDMR_THREADS=256 / DDDMR_TILE keep the 256-lane shape reachable for experiments.
+  int thr = 512;
+  auto lds_of = [&](int t) { return score_lds_bytes(t, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap); };
   auto tile_for_256 = [&]() {
-    // most (trajectory, step) slots resident per CU: workgroups per CU (4 by registers, fewer
-    // by LDS) x slots per workgroup, slots <= lanes
+    // most (trajectory, step) slots resident per CU: workgroups per CU (by registers, fewer by LDS) x slots per
+    // workgroup, slots <= lanes
     int t_best = 1;
     long best = 0;
     for (int t = 1; t <= kMaxTile; ++t) {
       if (t > 1 && t * s_tick > 256) break;
-      const size_t need = score_lds_bytes(t, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) + 1024;   // + static LDS
-      const long wgs = std::min<long>(4, (long)((size_t)(160 * 1024) / need));
+      const size_t need = lds_of(t) + 1024;   // + static LDS
+      const long wgs = std::min<long>(DDDMR_SCORE_WPE_256, (long)((size_t)(160 * 1024) / need));
       const long resident = wgs * t * s_tick;
       if (resident >= best) { best = resident; t_best = t; }
     }
     return t_best;
   };
-  int tile = tile_for_256();
+  int tile = 1;
   if (ctx->tile_override > 0) {
     tile = std::min(ctx->tile_override, kMaxTile);
     thr = ctx->threads_override > 0 ? ctx->threads_override : 256;
+  } else if (ctx->threads_override == 256) {
+    thr = 256;
+    tile = tile_for_256();
   } else if (k.n_local > 0) {
     const int slots512 = ctx->n_cu * 2;
     const int fit = (k.n_local + slots512 - 1) / slots512;
-    if (fit <= kMaxTile && fit * s_tick <= 2 * 512 &&
-        score_lds_bytes(fit, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) <= 80 * 1024 &&
-        (ctx->threads_override == 0 || ctx->threads_override == 512)) {
-      thr = 512;
+    if (fit <= kMaxTile && fit * s_tick <= 2 * 512 && lds_of(fit) <= (size_t)80 * 1024) {
       tile = std::max(fit, 1);
+    } else {
+      for (int t = 2; t <= kMaxTile; ++t) {
+        if (t * s_tick > 512 || lds_of(t) > (size_t)80 * 1024) break;
+        tile = t;
+      }
     }
-    if (ctx->threads_override == 256) { thr = 256; tile = tile_for_256(); }
   }
   while (tile > 1 && score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap) > (size_t)(160 * 1024) / 2) --tile;
   const size_t lds = score_lds_bytes(tile, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap);
@@ -1013,7 +1031,11 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     std::fprintf(stderr, "[dddmr] k_score shape: %d lanes, tile %d, %d-step rows, %zu bytes of dynamic LDS (tile+1 would need %zu)\n", thr, tile, s_tick, lds,
                  score_lds_bytes(tile + 1, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap));
   k.tile = tile;
-
+  // Who decodes the winner: shards that run as ONE round of workgroups let the last workgroup do it (a
+  // finalize launch would cost the tick ~3 us); bigger shards run several rounds, where every workgroup's ticket
+  // round trip holds a slot that the next workgroup is waiting for -- there a one-wave k_finalize follows.
+  const bool one_round = k.n_local <= 0 || (k.n_local + tile - 1) / tile <= ctx->n_cu * (thr == 512 ? 2 : 4);
+  k.final_kernel = ctx->final_mode >= 0 ? ctx->final_mode : (one_round ? 0 : 1);
 
   if (k.n_local > 0) {
     // small per-tick uploads (sample axes or explicit list)
@@ -1126,6 +1148,9 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     hipLaunchKernelGGL(k_empty_result, dim3(1), dim3(64), 0, ctx->stream, k, ctx->cell_start, score_result, score_words);
   }
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs1, ctx->stream));
+  if (k.n_local > 0 && k.final_kernel)
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, ctx->stream, k, ctx->best_key, ctx->costs, ctx->samples_out,
+                       ctx->cell_start, ctx->overflow, score_result, score_words);
   if (ctx->comm) {
     const int nrc = rccl().all_reduce(ctx->slots_dev, ctx->slots_red, (size_t)2 * ctx->comm_ranks, ncclInt64, ncclMin,
                                       ctx->comm, ctx->stream);

@@ -34,7 +34,14 @@ namespace dddmr {
 #define DDDMR_PSPLIT_MAX 4   // the path critic's 1-NN search is shared by up to 2^4 lanes per pair
 #endif
 #ifndef DDDMR_SCORE_WPE
-#define DDDMR_SCORE_WPE 2   // min waves per SIMD the register allocator must allow for k_score
+#define DDDMR_SCORE_WPE 2   // min waves per SIMD the register allocator must allow for the 512-lane k_score
+#endif
+// The 256-lane k_score runs big shards in several rounds of workgroups and is bound by how many waves hide each
+// other's latency: 5 waves per SIMD (96 VGPRs, the pose math of phase D1 spills ~25 loop-invariant doubles to
+// scratch) beat 4 (121 VGPRs, no spills) by 3 % at C3 and 7 % at C4; the single-round 512-lane shape loses 10 %
+// with it (C2) and keeps 4.
+#ifndef DDDMR_SCORE_WPE_256
+#define DDDMR_SCORE_WPE_256 5
 #endif
 // k_score is instantiated for 256- and 512-lane workgroups (template parameter
 // kScoreThreads): 512 lanes halve the collision walk of the heaviest tile and win when
@@ -103,6 +110,7 @@ struct DevTick {
   int roll_blocks;   // the rollout workgroups and (use_assign) one assignment workgroup
   int box_fast;      // the cuboid is a body-frame box in the reference's vertex order (host-checked)
   int rec_pose;      // OBB records carry the pose (some pair may need the 1 m radius test, or min-max critic)
+  int final_kernel;  // 1: the winner is decoded by k_finalize after k_score (multi-round shards), 0: by k_score's last workgroup
   uint32_t seq;      // tick sequence number echoed into DevResult::seq
   float axes_inl[kInlineAxes];
 };
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(DevTick k, const float4* __
 // cos/sin of the heading after the step (double2, the pose's AngleAxisd rotation).
 // ---------------------------------------------------------------------------
 #ifdef DDDMR_PHASE_STAMPS
-constexpr int kStampSlots = 10;
+constexpr int kStampSlots = 12;
 __device__ unsigned long long g_stamps[16384 * kStampSlots];
 #define DDDMR_STAMP(i)                                                                         \
   do {                                                                                         \
@@ -843,11 +851,70 @@ __device__ __forceinline__ void pose_translation(const DevTick& k, float2 bxy, d
   for (int i = 0; i < 3; ++i) T[i] = k.R[3 * i + 0] * (double)bxy.x + k.R[3 * i + 1] * (double)bxy.y + k.t[i];
 }
 
+// Winner decode (local_planner.cpp:447-480), run by ONE wave once every k_score workgroup has filed its keys:
+// either wave 0 of the workgroup that drew the last ticket (small shards: no extra launch) or k_finalize.
+//
+// Exactness: the reference compares full doubles (`cost_ <= minimum_cost`, :460).  The key's winner i is the
+// highest index among the costs that share the minimum's top 40 bits; if cost[i] IS the minimum (its bits equal
+// the reduced cost word -- always, unless two costs differ by less than 3.7e-9 relative without being equal) then
+// i is also the highest index among the exactly minimal costs, i.e. the reference's answer.  Otherwise the wave
+// rescans the shard's costs for the exact minimum (rare; 64 lanes, device-scope loads).
+__device__ __forceinline__ void decode_winner(const DevTick& k, const int lane, const int64_t* __restrict__ best_key,
+                                              const double* __restrict__ costs, const float4* __restrict__ samples_out,
+                                              const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ overflow,
+                                              DevResult* __restrict__ result, int64_t* __restrict__ words_out) {
+  const int64_t kmin = __hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t cmin = __hip_atomic_load(best_key + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long* cost_words = reinterpret_cast<const unsigned long long*>(costs);
+  int li = -1;
+  if (kmin != kKeyNone) {
+    li = key_index(kmin) - k.begin;
+    const long long cb = (long long)__hip_atomic_load(cost_words + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (cb != (long long)cmin) {
+      int found = -1;
+      for (int i = lane; i < k.n_local; i += 64)
+        if ((long long)__hip_atomic_load(cost_words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (long long)cmin) found = i;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) found = max(found, __shfl_xor(found, o, 64));
+      li = found;
+    }
+  }
+  if (lane == 0) {
+    DevResult r;
+    r.index = li >= 0 ? k.begin + li : -1;
+    r.cost = -1.0;
+    r.vx = r.vy = r.wz = 0.f;
+    r.key = kKeyNone;
+    if (li >= 0) {
+      r.cost = __longlong_as_double((long long)cmin);
+      r.key = pack_key(r.cost, (uint32_t)r.index);
+      const float* so = reinterpret_cast<const float*>(samples_out + li);
+      r.vx = __hip_atomic_load(so + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      r.vy = __hip_atomic_load(so + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      r.wz = __hip_atomic_load(so + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    r.n_binned = cell_start[k.n_cells];
+    r.overflow = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.seq = 0;
+    r.pad = 0;
+    *result = r;
+    if (words_out) {
+      // multi-rank context: this shard's (cost bits, -index) slot of the all-reduce that follows on
+      // the stream; `result` then is a device-side staging record and k_resolve tells the host
+      words_out[0] = li >= 0 ? (int64_t)cmin : kKeyNone;
+      words_out[1] = li >= 0 ? -(int64_t)r.index : kKeyNone;
+    } else {
+      __threadfence_system();
+      __hip_atomic_store(&result->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 // kLean: the common critic stack -- no min-max critic and no pair that needs the 1 m radius test
 // (the cuboid lies inside the search ball) -- as compile-time facts: the walk loses its radius /
 // min-max code and the records their optional words.
 template <int kScoreThreads, bool kLean>
-__global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
+__global__ __launch_bounds__(kScoreThreads, kScoreThreads == 512 ? DDDMR_SCORE_WPE : DDDMR_SCORE_WPE_256) void k_score(
     DevTick k, const TrajInfo* __restrict__ info, const double2* __restrict__ st_sc, const float2* __restrict__ st_xy,
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
     const Pt3* __restrict__ sorted, double* __restrict__ costs, int32_t* __restrict__ steps_out,
@@ -1373,6 +1440,7 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     if (lane == 0) head[j].stick_sum = (acc + r1) + (r2 + r3);
   }
   __syncthreads();
+  DDDMR_STAMP(10);  // end of the StickPath sums
 
   // ---- phase E: stacked scoring (stacked_scoring_model.cpp:75-93) + argmin ----
   int64_t key = kKeyNone, cbits = kKeyNone;
@@ -1436,19 +1504,25 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     }
     // cost + sample are read back by the last workgroup: device-scope (write-through)
     // stores, matched by device-scope loads there -- no cache flush needed
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(costs) + li,
-                       (unsigned long long)__double_as_longlong(cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    float* so = reinterpret_cast<float*>(samples_out + li);
-    __hip_atomic_store(so + 0, h.vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(so + 1, h.vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(so + 2, h.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    so[3] = 0.f;
+    if (k.final_kernel) {                      // the launch boundary before k_finalize publishes plain stores
+      costs[li] = cost;
+      samples_out[li] = make_float4(h.vx, h.vy, h.w, 0.f);
+    } else {
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(costs) + li,
+                         (unsigned long long)__double_as_longlong(cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float* so = reinterpret_cast<float*>(samples_out + li);
+      __hip_atomic_store(so + 0, h.vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(so + 1, h.vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(so + 2, h.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      so[3] = 0.f;
+    }
     steps_out[li] = h.steps;
     // what this trajectory cost (in collision work items): the walk, the path critics'
     // 1-NN searches when it got that far, and the per-pair phases
     const bool collided = (need_box && h.hit_box) || (need_mm && h.hit_mm);
     traj_load[li] = (uint32_t)h.walked + (uint32_t)h.steps * (2u + (collided ? 0u : (uint32_t)((k.m + 15) >> 4)));
   }
+  DDDMR_STAMP(11);  // end of the stacked scoring + per-trajectory stores
   // Wave-0 min-reduction, one pair of atomics per workgroup.  Two words are reduced: the packed
   // key (top 40 bits of the cost | inverted index: one atomicMin yields minimum cost AND, among
   // costs equal in those bits, the highest index) and the cost's full bit pattern.  The decode
@@ -1473,19 +1547,14 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
       atomicMin((long long*)best_key + 1, (long long)cbits);
     }
   }
-  // ---- winner decode by the last workgroup (local_planner.cpp:447-480) ----
-  // Placement-independent hand-off: every byte handed over (key, cost, sample,
-  // capacity flag) is written with device-scope atomics / write-through stores and
-  // read with device-scope loads; waves drain their stores, barrier, one relaxed
-  // device-scope ticket.  Wave 0 of the workgroup drawing the last ticket writes the result
-  // straight into host-mapped memory (no finalize launch, no D2H copy).
-  //
-  // Exactness: the reference compares full doubles (`cost_ <= minimum_cost`, :460).  The key's
-  // winner i is the highest index among the costs that share the minimum's top 40 bits; if
-  // cost[i] IS the minimum (its bits equal the reduced cost word -- always, unless two costs
-  // differ by less than 3.7e-9 relative without being equal) then i is also the highest index
-  // among the exactly minimal costs, i.e. the reference's answer.  Otherwise the wave rescans
-  // the shard's costs for the exact minimum (rare; 64 lanes, device-scope loads).
+  // ---- winner decode ----
+  // Big shards (several rounds of workgroups): nothing more to do here -- k_finalize decodes after the launch, so
+  // a workgroup neither waits for its stores nor pays a device-scope ticket round trip while it holds a slot.
+  if (k.final_kernel) { DDDMR_STAMP(7); return; }
+  // Small shards: the workgroup that draws the last ticket decodes (no finalize launch, no D2H copy).
+  // Placement-independent hand-off: every byte handed over (key, cost, sample, capacity flag) is written with
+  // device-scope atomics / write-through stores and read with device-scope loads; waves drain their stores,
+  // barrier, one relaxed device-scope ticket.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid < 64) {
@@ -1493,55 +1562,19 @@ __global__ __launch_bounds__(kScoreThreads, DDDMR_SCORE_WPE) void k_score(
     if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     if (t == gridDim.x - 1) {
-      const int64_t kmin = __hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int64_t cmin = __hip_atomic_load(best_key + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long* cost_words = reinterpret_cast<const unsigned long long*>(costs);
-      int li = -1;
-      if (kmin != kKeyNone) {
-        li = key_index(kmin) - k.begin;
-        const long long cb = (long long)__hip_atomic_load(cost_words + li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (cb != (long long)cmin) {
-          int found = -1;
-          for (int i = lane; i < k.n_local; i += 64)
-            if ((long long)__hip_atomic_load(cost_words + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (long long)cmin) found = i;
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) found = max(found, __shfl_xor(found, o, 64));
-          li = found;
-        }
-      }
-      if (lane == 0) {
-        *ticket = 0;
-        DevResult r;
-        r.index = li >= 0 ? k.begin + li : -1;
-        r.cost = -1.0;
-        r.vx = r.vy = r.wz = 0.f;
-        r.key = kKeyNone;
-        if (li >= 0) {
-          r.cost = __longlong_as_double((long long)cmin);
-          r.key = pack_key(r.cost, (uint32_t)r.index);
-          const float* so = reinterpret_cast<const float*>(samples_out + li);
-          r.vx = __hip_atomic_load(so + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          r.vy = __hip_atomic_load(so + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          r.wz = __hip_atomic_load(so + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        r.n_binned = cell_start[k.n_cells];
-        r.overflow = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.seq = 0;
-        r.pad = 0;
-        *result = r;
-        if (words_out) {
-          // multi-rank context: this shard's (cost bits, -index) slot of the all-reduce that follows on
-          // the stream; `result` then is a device-side staging record and k_resolve tells the host
-          words_out[0] = li >= 0 ? (int64_t)cmin : kKeyNone;
-          words_out[1] = li >= 0 ? -(int64_t)r.index : kKeyNone;
-        } else {
-          __threadfence_system();
-          __hip_atomic_store(&result->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
+      if (lane == 0) *ticket = 0;
+      decode_winner(k, lane, best_key, costs, samples_out, cell_start, overflow, result, words_out);
     }
   }
   DDDMR_STAMP(7);
+}
+
+// Winner decode as its own one-wave launch (multi-round shards, DevTick::final_kernel).
+__global__ __launch_bounds__(64) void k_finalize(DevTick k, const int64_t* __restrict__ best_key, const double* __restrict__ costs,
+                                                 const float4* __restrict__ samples_out, const uint32_t* __restrict__ cell_start,
+                                                 const uint32_t* __restrict__ overflow, DevResult* __restrict__ result,
+                                                 int64_t* __restrict__ words_out) {
+  decode_winner(k, (int)threadIdx.x, best_key, costs, samples_out, cell_start, overflow, result, words_out);
 }
 
 // n_local == 0 (a rank without samples): result only.

@@ -17,7 +17,7 @@ with LocalPlanner([sc.theory], max_points=max(len(sc.cloud), 16)) as lp:
     name = sc.theory.name.decode()
     for _ in range(5):
         r = lp.tick(name, sc.tick)
-    SL = 10
+    SL = 12
     n_wg = 16384
     buf = np.zeros(n_wg * SL, dtype=np.uint64)
     lib.dddmr_rollout_diag_stamps.argtypes = [C.c_void_p, C.c_size_t]
@@ -36,6 +36,8 @@ with LocalPlanner([sc.theory], max_points=max(len(sc.cloud), 16)) as lp:
         print(f"  {nm:18s} mean {d.mean():8.2f} kc  p50 {np.percentile(d,50):8.2f}  p99 {np.percentile(d,99):8.2f}  max {d.max():8.2f}")
     dP = (st[:, 8] - st[:, 6]) / 1000.0; dE = (st[:, 7] - st[:, 8]) / 1000.0
     print(f"    of which P path 1-NN mean {dP.mean():8.2f} kc max {dP.max():8.2f};  E stick+score+argmin mean {dE.mean():8.2f} max {dE.max():8.2f}")
+    e1 = (st[:, 10] - st[:, 8]) / 1000.0; e2 = (st[:, 11] - st[:, 10]) / 1000.0; e3 = (st[:, 7] - st[:, 11]) / 1000.0
+    print(f"    E split: StickPath sums mean {e1.mean():6.2f} kc | stacked scoring + stores mean {e2.mean():6.2f} | reduce + atomics (+ ticket) mean {e3.mean():6.2f} max {e3.max():6.2f}")
     life = (st[:, 7] - st[:, 0]) / 1000.0
     print(f"  workgroup lifetime mean {life.mean():.2f} us max {life.max():.2f} us; first start -> last end {(st[:,7].max()-t0)/1000.0:.2f} us")
     start = (st[:, 0] - t0) / 1000.0

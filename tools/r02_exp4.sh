@@ -1,0 +1,5 @@
+#!/bin/bash
+mkdir -p gpurun_out/r02
+run() { python bench.py --workload $1 --steps 300 --no-cpu-baseline --no-ceiling 2>gpurun_out/r02/exp4.err | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('%.1f M traj/s  ms/step %.5f  k_score %.5f  match %s' % (d['value']/1e6, d['ms_per_step'], d['roofline']['kernel_ms'], d['config']['cmd_vel_matches_oracle']))"; grep "k_score shape" gpurun_out/r02/exp4.err | head -1; }
+for W in C2 C3 C4 C5; do echo -n "$W: "; DDDMR_DEBUG_GRID=1 run $W; done
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
