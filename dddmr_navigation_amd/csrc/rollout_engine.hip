@@ -174,6 +174,7 @@ struct dddmr_rollout_ctx {
   uint2* pt_slot = nullptr;
   Pt3* sorted = nullptr;
   uint32_t *cell_count = nullptr, *cell_start = nullptr;
+  uint32_t* row_tab = nullptr;       // compact row-run index of the tick's grid (k_bin_scatter -> k_score)
   float* axes_dev = nullptr;
   float4* samples_dev = nullptr;
   float4* plan_dev = nullptr;
@@ -442,7 +443,7 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
     if (ctx->cloud_dev[i]) (void)hipFree(ctx->cloud_dev[i]);
     if (ctx->cloud_ready[i]) (void)hipEventDestroy(ctx->cloud_ready[i]);
   }
-  void* dev[] = {ctx->pt_slot, ctx->sorted, ctx->cell_count, ctx->cell_start, ctx->axes_dev,
+  void* dev[] = {ctx->row_tab, ctx->pt_slot, ctx->sorted, ctx->cell_count, ctx->cell_start, ctx->axes_dev,
                  ctx->samples_dev, ctx->plan_dev, ctx->costs, ctx->steps, ctx->samples_out,
                  ctx->best_key, ctx->overflow, ctx->tickets, ctx->poses_dev, ctx->traj_load, ctx->assign, ctx->blocked_plan, ctx->blocked_flags};
   for (void* p : dev)
@@ -524,6 +525,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMalloc(&ctx->cell_count, (kCapCells + 1) * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->cell_start, (kCapCells + 1) * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(ctx->cell_count, 0, (kCapCells + 1) * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&ctx->row_tab, (size_t)kTabCap * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->axes_dev, 3 * kMaxAxis * sizeof(float)));
     HIPCHK(ctx, hipMalloc(&ctx->samples_dev, N * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&ctx->plan_dev, plan_cap * sizeof(float4)));
@@ -988,6 +990,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   //  - a shard that fits ONE round of resident workgroups is spread evenly over them (C2: tile 8, 512 workgroups);
   //  - a bigger shard takes the largest tile whose (trajectory, step) pairs still fit the lanes (one pair per lane
   //    in D1 / D2) and whose LDS fits twice into a CU.
+  // (1024-lane workgroups, one per CU, lose again: C3 143 us at tile 12, C4 390 us at tile 16.)
   // DDDMR_THREADS=256 / DDDMR_TILE keep the 256-lane shape reachable for experiments.
   int thr = 512;
   auto lds_of = [&](int t) { return score_lds_bytes(t, s_tick, k.m, rec_words, k.tab_entries, k.rows_cap); };
@@ -1118,7 +1121,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
                        ctx->best_key, ctx->overflow, ctx->axes_dev, ctx->samples_dev, ctx->traj_info, ctx->st_sc,
                        ctx->st_xy, ctx->traj_load, ctx->assign);
     hipLaunchKernelGGL(k_bin_scatter, dim3(bin_blocks), dim3(256), 0, ctx->stream, k, ctx->cloud_dev[cidx],
-                       ctx->pt_slot, ctx->cell_start, ctx->sorted);
+                       ctx->pt_slot, ctx->cell_start, ctx->sorted, ctx->row_tab);
   } else {
     hipLaunchKernelGGL(k_bin_reset, dim3(1), dim3(256), 0, ctx->stream, k, ctx->cell_count, ctx->cell_start,
                        ctx->best_key, ctx->overflow);
@@ -1140,7 +1143,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   hipLaunchKernelGGL((k_score<T, L>), dim3(wgs), dim3(T), lds, ctx->stream, k, ctx->traj_info, ctx->st_sc,        \
                      ctx->st_xy, ctx->plan_dev, ctx->cell_start, ctx->sorted, ctx->costs, ctx->steps,             \
                      ctx->samples_out, ctx->best_key, ctx->overflow, ctx->tickets + 1, score_result, ctx->assign, \
-                     ctx->traj_load, score_words)
+                     ctx->traj_load, score_words, ctx->row_tab)
     if (thr == 512) { if (lean) DDDMR_LAUNCH_SCORE(512, true); else DDDMR_LAUNCH_SCORE(512, false); }
     else            { if (lean) DDDMR_LAUNCH_SCORE(256, true); else DDDMR_LAUNCH_SCORE(256, false); }
 #undef DDDMR_LAUNCH_SCORE

@@ -354,8 +354,15 @@ __global__ __launch_bounds__(256) void k_bin_reset(DevTick k, uint32_t* __restri
 __global__ __launch_bounds__(256) void k_bin_scatter(DevTick k, const float4* __restrict__ cloud,
                                                      const uint2* __restrict__ pt_slot,
                                                      const uint32_t* __restrict__ cell_start,
-                                                     Pt3* __restrict__ sorted) {
+                                                     Pt3* __restrict__ sorted, uint32_t* __restrict__ row_tab) {
   const int stride = gridDim.x * blockDim.x;
+  // The costmap's row-run index, compact: entry (cy, cx) = first sorted point of cell column (cx, cy), cx = gnx being
+  // the end of the row.  Every k_score workgroup stages it; gathering it there from cell_start (stride gnz words)
+  // cost each of them ~1000 scattered 64-byte sectors.
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k.tab_entries; i += stride) {
+    const int cy = i / (k.gnx + 1), cx = i - cy * (k.gnx + 1);
+    row_tab[i] = cell_start[(cy * k.gnx + cx) * k.gnz];
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < k.n_points; i += stride) {
     const uint2 slot = pt_slot[i];
     if (slot.x != 0xFFFFFFFFu) {
@@ -779,6 +786,8 @@ struct TrajHead {     // per-trajectory header in LDS
 // [17] trajectory | radius-skip flag, then (only when some pair can need the radius test)
 // [18..20] pose, then (only for CollisionMinMaxModel) the world AABB
 constexpr int kRecBase = 18;
+// (an ODD stride -- 19 words, no two lanes of D1 / D2 on one LDS bank -- was measured and changes nothing: C3 k_score
+// 127.1 -> 128.3 us; the walk's record reads are mostly same-pair broadcasts)
 __host__ __device__ inline int rec_words_of(bool rec_pose, bool want_mm) { return kRecBase + (rec_pose ? 3 : 0) + (want_mm ? 6 : 0); }
 constexpr int kRows = 8;            // y-rows of cells one cuboid AABB may span (host sizes the cells for it)
 #ifndef DDDMR_ITEM
@@ -914,13 +923,13 @@ __device__ __forceinline__ void decode_winner(const DevTick& k, const int lane, 
 // (the cuboid lies inside the search ball) -- as compile-time facts: the walk loses its radius /
 // min-max code and the records their optional words.
 template <int kScoreThreads, bool kLean>
-__global__ __launch_bounds__(kScoreThreads, kScoreThreads == 512 ? DDDMR_SCORE_WPE : DDDMR_SCORE_WPE_256) void k_score(
+__global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_WPE : DDDMR_SCORE_WPE_256) void k_score(
     DevTick k, const TrajInfo* __restrict__ info, const double2* __restrict__ st_sc, const float2* __restrict__ st_xy,
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
     const Pt3* __restrict__ sorted, double* __restrict__ costs, int32_t* __restrict__ steps_out,
     float4* __restrict__ samples_out, int64_t* __restrict__ best_key, uint32_t* __restrict__ overflow,
     uint32_t* __restrict__ ticket, DevResult* __restrict__ result, const uint32_t* __restrict__ assign,
-    uint32_t* __restrict__ traj_load, int64_t* __restrict__ words_out) {
+    uint32_t* __restrict__ traj_load, int64_t* __restrict__ words_out, const uint32_t* __restrict__ row_tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   const int tile = k.tile;
   const int S1 = k.max_steps + 1;
@@ -991,10 +1000,7 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads == 512 ? DDDMR_SCORE_W
   const int tab_n = k.tab_entries;          // (gnx+1)*gny, or 0 when the index does not fit
   const bool tab_staged = tab_n > 0;
   if (tab_staged && k.n_points >= 5 && (need_box || need_mm)) {
-    for (int i = tid; i < tab_n; i += kScoreThreads) {
-      const int cy = i / (k.gnx + 1), cx = i - cy * (k.gnx + 1);
-      tab[i] = cell_start[(cy * k.gnx + cx) * k.gnz];
-    }
+    for (int i = tid; i < tab_n; i += kScoreThreads) tab[i] = row_tab[i];       // (built by k_bin_scatter)
   }
   __syncthreads();
   DDDMR_STAMP(1);   // end of phase A
@@ -1398,7 +1404,22 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads == 512 ? DDDMR_SCORE_W
       }
       // exact 1-NN distance to the prune plan (FLANN float distance)
       float best = 3.402823466e+38f;
-      if (valid) {
+      if (valid && lg == 0) {
+        // One lane per pose, every lane walks the WHOLE plan: the plan point is the same for all lanes, so it comes
+        // through the scalar unit (uniform index into the kernel argument -> s_load, operands in SGPRs) instead of
+        // 64 lanes reading one LDS address -- broadcast 16-byte LDS reads were what bound this phase.
+        int i = 0;
+        for (; i + 4 <= k.m; i += 4) {
+          const float4 p0 = plan_xyz[i], p1 = plan_xyz[i + 1], p2 = plan_xyz[i + 2], p3 = plan_xyz[i + 3];
+          const f2 da = l2_simple2(f2{p0.x, p1.x}, f2{p0.y, p1.y}, f2{p0.z, p1.z}, px, py, pz);
+          const f2 db = l2_simple2(f2{p2.x, p3.x}, f2{p2.y, p3.y}, f2{p2.z, p3.z}, px, py, pz);
+          best = fminf(fminf(best, fminf(da.x, da.y)), fminf(db.x, db.y));
+        }
+        for (; i < k.m; ++i) {
+          const float4 pp = plan_xyz[i];
+          best = fminf(best, l2_simple(pp.x, pp.y, pp.z, px, py, pz));
+        }
+      } else if (valid) {
         int i = g * per;
         const int i1 = min(k.m, i + per);
         for (; i + 4 <= i1; i += 4) {
@@ -1457,7 +1478,12 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads == 512 ? DDDMR_SCORE_W
       // mpc_critics_ros.cpp:60-81); its non-negative return is then added and thrown away by
       // the collision critic's -1 further down the stack, so 0 stands in for it here.
       const bool dead = cloud_ok && ((need_box && h.hit_box) || (need_mm && h.hit_mm));
-      for (int m = 0; m < k.n_critics; ++m) {
+      // (unrolled over the <= 8 stack slots: k.ckind[m] / k.cw[m] with a compile-time m are plain kernel-argument
+      // reads the scalar unit fetches up front, instead of one dependent scalar load chain per loop trip)
+      bool done = false;
+#pragma unroll
+      for (int m = 0; m < DDDMR_MAX_CRITICS; ++m) {
+        if (m >= k.n_critics || done) continue;
         double r = 0.0;
         switch (k.ckind[m]) {
           case DDDMR_CRITIC_COLLISION:
@@ -1496,8 +1522,8 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads == 512 ? DDDMR_SCORE_W
           default:
             r = 0.0;
         }
-        if (r < 0) { cost = r; break; }
-        cost += r;
+        if (r < 0) { cost = r; done = true; }
+        else cost += r;
       }
       key = pack_key(cost, (uint32_t)gi);
       cbits = cost_bits(cost);
