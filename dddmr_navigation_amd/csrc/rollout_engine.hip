@@ -1409,7 +1409,10 @@ int dddmr_rollout_stream_ceiling(dddmr_rollout_ctx* ctx, size_t bytes, int32_t r
   if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "stream_ceiling while a tick_begin is pending");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   const size_t n = bytes / sizeof(float4);
-  const int blocks = ctx->n_cu * 8;
+  // one pass of the four-loads-in-flight loop per lane measured best (grid sweep 1k ... 64k workgroups:
+  // copy 4.5 -> 5.2 TB/s, read 5.7 -> 6.0 TB/s; tools/exp_ceiling.py)
+  int blocks = (int)std::min<size_t>(65536, std::max<size_t>(1, n / (256 * 4)));
+  if (const char* e = std::getenv("DDDMR_CEIL_BLOCKS")) blocks = std::max(1, std::atoi(e));
   float4 *src = nullptr, *dst = nullptr;
   float* sink = nullptr;
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -2,7 +2,9 @@
 and the heading predicates): tiny, sequential, and their outputs are INPUTS of the
 rollout engine.  Restated from
 /root/reference/src/dddmr_local_planner/local_planner/src/local_planner.cpp
-with the same quirks (cited inline); the C++ twin is in include/dddmr_rollout.hpp.
+with the same quirks (cited inline).  Test support for the Python mirror only: in a real
+deployment these functions stay what they are in the reference -- unchanged host C++ inside
+Local_Planner -- and nothing in the C-ABI or in include/dddmr_rollout.hpp replaces them.
 """
 from __future__ import annotations
 
