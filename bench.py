@@ -187,38 +187,45 @@ def main():
     # ONE min all-reduce of the 2*world-word slot vector (16 bytes per rank) hands every rank all
     # pairs, and dddmr_rollout_resolve_words picks minimum cost / highest index among equals -- the
     # reference's `<=` scan (local_planner.cpp:456-463) over the whole batch, full doubles.
+    def inlib_bootstrap():
+        """Bring the library's own RCCL communicator up on every rank; True if all ranks made it.
+        Rank 0 draws the RCCL unique id and hands it to the others (any broadcast will do; a C++ host
+        would use its own channel); an all-zero id means "rank 0 cannot" and every rank agrees."""
+        uid = bytes(128)
+        if rank == 0:
+            try:
+                uid = lp.comm_unique_id()
+            except RolloutError as e:
+                print(f"[bench] in-library RCCL unavailable ({e})", file=sys.stderr, flush=True)
+        t = torch.tensor(list(uid), dtype=torch.uint8, device=red_dev)
+        dist.broadcast(t, src=0)
+        uid = bytes(t.cpu().tolist())
+        up = False
+        if any(uid):
+            try:
+                lp.comm_init(uid, rank, world)
+                up = True
+            except RolloutError as e:
+                print(f"[bench] rank {rank}: dddmr_rollout_comm_init failed ({e})", file=sys.stderr, flush=True)
+        ok = torch.tensor([1 if up else 0], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and up:
+            lp.comm_destroy()
+        return int(ok.item()) == 1
+
+    # Which exchange the TIMED loop uses.  torch (default, `auto`): the host hides the all-reduce behind the
+    # next tick (throughput; winners arrive two ticks late).  inlib: k_score -> ncclAllReduce -> k_resolve on
+    # the tick's stream, every tick synchronous.  With `auto` the in-library path is measured as well, AFTER the
+    # timed loop and under a watchdog (a collective that never returns must not cost the run its line).
     reduce_mode = "none"
     if world > 1:
         reduce_mode = "torch"
-        if args.reduce in ("auto", "inlib") and args.backend == "nccl":
-            # rank 0 draws the RCCL unique id and hands it to the others (any broadcast will do; a C++
-            # host would use its own channel); an all-zero id means "rank 0 cannot" and every rank agrees
-            uid = bytes(128)
-            if rank == 0:
-                try:
-                    uid = lp.comm_unique_id()
-                except RolloutError as e:
-                    print(f"[bench] in-library RCCL unavailable ({e})", file=sys.stderr, flush=True)
-            t = torch.tensor(list(uid), dtype=torch.uint8, device=red_dev)
-            dist.broadcast(t, src=0)
-            uid = bytes(t.cpu().tolist())
-            if any(uid):
-                try:
-                    lp.comm_init(uid, rank, world)
-                    reduce_mode = "inlib"
-                except RolloutError as e:
-                    print(f"[bench] rank {rank}: dddmr_rollout_comm_init failed ({e})", file=sys.stderr, flush=True)
-            ok = torch.tensor([1 if reduce_mode == "inlib" else 0], dtype=torch.int64, device=red_dev)
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if reduce_mode == "inlib":
-                    lp.comm_destroy()
-                reduce_mode = "torch"
-                if args.reduce == "inlib":
-                    raise SystemExit("[bench] --reduce inlib: the library's RCCL communicator did not come up on every rank")
-                print("[bench] reducing through torch.distributed instead", file=sys.stderr, flush=True)
-        elif args.reduce == "inlib":
-            raise SystemExit("--reduce inlib needs --backend nccl (RCCL)")
+        if args.reduce == "inlib":
+            if args.backend != "nccl":
+                raise SystemExit("--reduce inlib needs --backend nccl (RCCL)")
+            if not inlib_bootstrap():
+                raise SystemExit("[bench] --reduce inlib: the library's RCCL communicator did not come up on every rank")
+            reduce_mode = "inlib"
 
     # torch path: everything the host does for the all-reduce -- collecting the reduce of tick i-2,
     # issuing the one of tick i-1 -- happens between tick_begin(i) and tick_end(i), i.e. while the
@@ -480,6 +487,44 @@ def main():
         }
         if marking is not None:
             out["config"]["marking"] = marking.summary()
+
+    # ---- the in-library RCCL exchange, measured after the timed loop (`--reduce auto`, RCCL backend) ----
+    # k_score -> ncclAllReduce(min) -> k_resolve on the tick's stream: the synchronous tick a C++ host gets without
+    # any collective code of its own.  A watchdog prints the line gathered so far and leaves if the bootstrap or a
+    # collective never returns (first use of this path on a multi-GPU node).
+    if world > 1 and reduce_mode == "torch" and args.reduce == "auto" and args.backend == "nccl":
+        import threading
+        done = threading.Event()
+
+        def watchdog():
+            if not done.wait(90.0):
+                if out is not None:
+                    out["config"]["inlib_rccl"] = {"status": "timed out after 90 s"}
+                    print(json.dumps(out), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+        inlib = {"status": "communicator did not come up on every rank"}
+        try:
+            dist.barrier()
+            if inlib_bootstrap():
+                lat, r2 = [], None
+                for _ in range(110):
+                    dist.barrier()
+                    t1 = time.perf_counter()
+                    r2 = lp.tick(name, sc.tick)          # returns the GLOBAL winner on every rank
+                    lat.append((time.perf_counter() - t1) * 1e3)
+                lt = torch.tensor([median(lat[10:])], dtype=torch.float64, device=red_dev)
+                dist.all_reduce(lt, op=dist.ReduceOp.MAX)
+                inlib = {"status": "ok", "sync_tick_ms": round(float(lt.item()), 5),
+                         "trajectories_per_s_synchronous": round(n_global / (float(lt.item()) * 1e-3), 1),
+                         "winner_equals_torch_path": bool(r2.best_index == res.best_index and r2.best_cost == res.best_cost),
+                         "note": "k_score -> ncclAllReduce(ncclInt64, ncclMin) of the slot vector -> k_resolve on the context's stream"}
+                lp.comm_destroy()
+        except Exception as e:      # noqa: BLE001 -- report, never lose the line
+            inlib = {"status": f"{type(e).__name__}: {e}"}
+        done.set()
+        if out is not None:
+            out["config"]["inlib_rccl"] = inlib
     for extra in lps[1:]:
         extra.close()
     if marking is not None:

@@ -78,6 +78,18 @@ def test_shipped_config_ten_scans_with_a_vanishing_obstacle():
     assert totals["marked"] > 5000 and totals["cleared"] > 3000 and final[0] > 1000 and final[2] > 100
 
 
+def test_pool_compaction_keeps_the_store_identical():
+    """A pool of generator points barely larger than what the alive markings need: cleared and replaced markings
+    leave garbage behind, so the compaction pass (alive markings move to the front of the second pool buffer) runs
+    every few updates -- results must not move."""
+    _, _, walls, _ = _scene()
+    cfg = marking.shipped_config(max_cluster_points=24000)
+    poses = lambda k: (0.3 * k, 0.0, 0.0, 0, 0, 0, 1)
+    scene_of = lambda k, cloud: cloud if k < 5 else cloud[np.hypot(cloud[:, 0] - 2.5, cloud[:, 1]) > 1.5]
+    totals, final = _run_sequence(cfg, walls, poses, scene_of)
+    assert totals["marked"] > 5000 and final[0] > 1000
+
+
 def test_coarse_clusters_static_map_and_tilted_robot():
     """Tolerance 0.25 / min cluster size 3 (large wall clusters -> long summation chains), static-map
     rejection on (segmentation_ignore_ratio 0.5, the corridor walls are the static map), robot pitched and
