@@ -96,6 +96,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
+    # stdout carries exactly ONE line: the JSON.  Whatever libraries print there on the way (RCCL writes a version
+    # banner on its first communicator, gloo its connection report) is sent to stderr instead.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -500,7 +506,8 @@ def main():
             if not done.wait(90.0):
                 if out is not None:
                     out["config"]["inlib_rccl"] = {"status": "timed out after 90 s"}
-                    print(json.dumps(out), flush=True)
+                    json_out.write(json.dumps(out) + "\n")
+                    json_out.flush()
                 os._exit(0)
         threading.Thread(target=watchdog, daemon=True).start()
         inlib = {"status": "communicator did not come up on every rank"}
@@ -534,7 +541,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if out is not None:
-        print(json.dumps(out), flush=True)
+        json_out.write(json.dumps(out) + "\n")
+        json_out.flush()
 
 
 if __name__ == "__main__":

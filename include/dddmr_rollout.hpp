@@ -105,12 +105,78 @@ class LocalPlanner {
     return static_cast<PlannerState>(last_.planner_state);
   }
 
-  // multi-rank hosts: min-reduce lastResult().key over the ranks, then resolve
+  // cbSensor's stitcher_num (multilayer_spinning_lidar.cpp:185-200): later setScan() calls feed the last n raw scans
+  void setStitcher(int stitcher_num) { check(dddmr_rollout_set_stitcher(ctx_, stitcher_num)); }
+
+  // the theory's initialise() alone: the (vx, vy, wz) sample list a tick with these inputs rolls out
+  std::vector<std::array<float, 3>> samples(const std::string& traj_gen_name, const dddmr_tick_input& in) {
+    size_t n = 0;
+    check(dddmr_rollout_samples(ctx_, traj_gen_name.c_str(), &in, nullptr, 0, &n));
+    std::vector<std::array<float, 3>> out(n);
+    if (n) check(dddmr_rollout_samples(ctx_, traj_gen_name.c_str(), &in, &out[0][0], n, &n));
+    return out;
+  }
+
+  // ---- multi-rank hosts (one context per GPU, created with rank / world_size) ----
   const dddmr_rollout_result& lastResult() const { return last_; }
+  // (a) in-library exchange: RCCL communicator owned by the context; afterwards every tick returns the GLOBAL winner
+  static std::array<uint8_t, DDDMR_COMM_ID_BYTES> commUniqueId() {
+    std::array<uint8_t, DDDMR_COMM_ID_BYTES> id{};
+    const int rc = dddmr_rollout_comm_unique_id(id.data());
+    if (rc != DDDMR_OK) throw RolloutError(rc, "dddmr_rollout_comm_unique_id failed (librccl not loadable?)");
+    return id;
+  }
+  void commInit(const std::array<uint8_t, DDDMR_COMM_ID_BYTES>& id, int rank, int n_ranks) {
+    check(dddmr_rollout_comm_init(ctx_, id.data(), rank, n_ranks));
+  }
+  void commDestroy() { check(dddmr_rollout_comm_destroy(ctx_)); }
+  // (b) host-side exchange: min-all-reduce a 2 * n_ranks int64 vector holding every rank's winnerWords() in its
+  // slots (INT64_MAX elsewhere), then resolveWords() on every rank -- exact; or the 8-byte key + resolve()
+  std::array<int64_t, 2> winnerWords() const {
+    std::array<int64_t, 2> w{};
+    dddmr_rollout_winner_words(&last_, w.data());
+    return w;
+  }
+  dddmr_rollout_result resolveWords(const std::vector<int64_t>& slots) {
+    dddmr_rollout_result r = last_;
+    check(dddmr_rollout_resolve_words(ctx_, slots.data(), (int32_t)(slots.size() / 2), &r));
+    return r;
+  }
   dddmr_rollout_result resolve(int64_t reduced_key) {
     dddmr_rollout_result r = last_;
     check(dddmr_rollout_resolve(ctx_, reduced_key, &r));
     return r;
+  }
+
+  // ---- global-mode marking / clearing layer of the lidar plugin (multilayer_spinning_lidar.cpp:306-746) ----
+  void markingCreate(const dddmr_marking_config& cfg, const float* ground_xyz, size_t n_ground, size_t ground_stride,
+                     const float* map_xyz, size_t n_map, size_t map_stride) {
+    check(dddmr_rollout_marking_create(ctx_, &cfg, ground_xyz, n_ground, ground_stride, map_xyz, n_map, map_stride));
+    n_ground_ = n_ground;
+  }
+  // one doClear_then_Mark pass on the current aggregate observation (setScan / setCloud)
+  dddmr_marking_stats markingUpdate(const double T_base_sensor[7], const double T_gbl_base[7]) {
+    dddmr_marking_stats st{};
+    check(dddmr_rollout_marking_update(ctx_, T_base_sensor, T_gbl_base, &st));
+    return st;
+  }
+  void markingReset() { check(dddmr_rollout_marking_reset(ctx_)); }
+  std::vector<double> dGraph() {                        // get_dGraphValue(index) for index 0..n_ground
+    std::vector<double> v(n_ground_ + 1);
+    check(dddmr_rollout_marking_get_dgraph(ctx_, v.data(), v.size()));
+    return v;
+  }
+  std::vector<uint8_t> lethal() {                       // lethal_map_ keys as flags
+    std::vector<uint8_t> v(n_ground_ + 1);
+    check(dddmr_rollout_marking_get_lethal(ctx_, v.data(), v.size()));
+    return v;
+  }
+  std::vector<std::array<int32_t, 3>> markedVoxels() {  // alive markings (the global_marking topic's keys)
+    size_t n = 0;
+    check(dddmr_rollout_marking_get_voxels(ctx_, nullptr, 0, &n));
+    std::vector<std::array<int32_t, 3>> v(n);
+    if (n) check(dddmr_rollout_marking_get_voxels(ctx_, &v[0][0], n, &n));
+    return v;
   }
 
   // best trajectory poses for the "best_trajectory" debug topic
@@ -150,6 +216,7 @@ class LocalPlanner {
   std::vector<dddmr_theory_config> theories_;
   dddmr_rollout_ctx* ctx_ = nullptr;
   dddmr_rollout_result last_{};
+  size_t n_ground_ = 0;
 };
 
 }  // namespace dddmr_amd

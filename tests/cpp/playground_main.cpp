@@ -68,6 +68,50 @@ int main(int argc, char** argv) {
     } catch (const dddmr_amd::RolloutError& e) {
       std::printf("error %d\n", e.code);
     }
+    // In-library RCCL exchange from plain C++ (no torch, no gloo): a 1-rank communicator; the tick then runs
+    // k_score -> ncclAllReduce(min) -> k_resolve and must return the same winner.
+    lp.setCloud(&cloud[0][0], 5, 32);
+    lp.commInit(dddmr_amd::LocalPlanner::commUniqueId(), 0, 1);
+    dddmr_amd::Trajectory via_comm;
+    lp.computeVelocityCommand("differential_drive_simple", via_comm, in);
+    const auto words = lp.winnerWords();
+    const auto resolved = lp.resolveWords({words[0], words[1]});
+    std::printf("comm %d %.17g %d %.17g %zu\n", via_comm.index_, via_comm.cost_, resolved.best_index, resolved.best_cost,
+                lp.samples("differential_drive_simple", in).size());
+    lp.commDestroy();
+    // Global-mode marking / clearing layer from plain C++: a 6 x 6 m ground lattice, one compact obstacle at (0, 2)
+    // and one at (-3, 3); mark both, then let the first one vanish and clear it.
+    std::vector<float> ground, obs;
+    for (int i = 0; i <= 40; ++i)
+      for (int j = 0; j <= 40; ++j) { ground.push_back(-5.f + 0.25f * i); ground.push_back(-5.f + 0.25f * j); ground.push_back(0.f); }
+    auto blob = [&](float cx, float cy) {
+      for (int z = 2; z < 10; ++z)
+        for (int a = -1; a <= 1; a += 2)
+          for (int b = -1; b <= 1; b += 2) { obs.push_back(cx + 0.03f * a); obs.push_back(cy + 0.03f * b); obs.push_back(0.1f * z); obs.push_back(0.f); }
+    };
+    dddmr_marking_config mc;
+    std::memset(&mc, 0, sizeof(mc));
+    mc.xy_resolution = 0.05; mc.height_resolution = 0.05; mc.marking_height = 2.0; mc.perception_window_size = 5.0;
+    mc.vertical_FOV_top = 15.0; mc.vertical_FOV_bottom = -15.0;
+    mc.scan_effective_positive_start = 30.0; mc.scan_effective_positive_end = 180.0;
+    mc.scan_effective_negative_start = -30.0; mc.scan_effective_negative_end = -180.0;
+    mc.euclidean_cluster_extraction_tolerance = 0.25; mc.euclidean_cluster_extraction_min_cluster_size = 1;
+    mc.segmentation_ignore_ratio = 1.1; mc.inscribed_radius = 0.5; mc.inflation_radius = 1.5; mc.max_obstacle_distance = 9999.0;
+    mc.max_markings = 1024; mc.max_cluster_points = 1 << 16;
+    lp.markingCreate(mc, ground.data(), ground.size() / 3, 12, nullptr, 0, 12);
+    const double t_bs[7] = {0, 0, 0.5, 0, 0, 0, 1}, t_gb[7] = {0, 0, 0, 0, 0, 0, 1};
+    blob(0.f, 2.f); blob(-3.f, 3.f);
+    lp.setCloud(obs.data(), obs.size() / 4, 16);
+    const dddmr_marking_stats m1 = lp.markingUpdate(t_bs, t_gb);
+    size_t touched = 0, lethal = 0;
+    for (double d : lp.dGraph()) touched += d < 9999.0 ? 1 : 0;
+    for (uint8_t f : lp.lethal()) lethal += f;
+    obs.clear(); blob(-3.f, 3.f);                      // the obstacle at (0, 2) leaves
+    lp.setCloud(obs.data(), obs.size() / 4, 16);
+    lp.markingUpdate(t_bs, t_gb);                      // cleared against the OLD observation: still blocked
+    const dddmr_marking_stats m3 = lp.markingUpdate(t_bs, t_gb);
+    std::printf("marking %u %u %u %zu %zu %u %u %zu\n", m1.n_clusters, m1.n_marked, m1.n_alive, touched, lethal, m3.n_cleared,
+                m3.n_alive, lp.markedVoxels().size());
   } catch (const std::exception& e) {
     std::fprintf(stderr, "fatal: %s\n", e.what());
     return 1;

@@ -32,3 +32,27 @@ def test_cpp_playground_matches_oracle(tmp_path, goal):
     tag, ratio, op = out[1].split()
     assert tag == "blocked" and float(ratio) == 25.0 and int(op) == K.OPINION_PATH_BLOCKED_WAIT
     assert out[2].strip() == f"error {K.ERR_UNKNOWN_THEORY}"
+    # in-library RCCL exchange from plain C++ (1-rank communicator): same winner, exact cost, host-side words agree
+    # (RCCL prints a version banner on stdout when its first communicator comes up: pick the lines by tag)
+    tagged = {l.split()[0]: l.split() for l in out if l.strip()}
+    tag, cidx, ccost, ridx, rcost, nsmp = tagged["comm"]
+    assert tag == "comm" and int(cidx) == int(ridx) == r.best_index and int(nsmp) == 55
+    assert float(ccost) == float(rcost) == float(cost)
+    # marking / clearing layer from plain C++ against the oracle on the same inputs
+    from dddmr_navigation_amd import marking
+    import numpy as np
+    g = np.array([[-5 + 0.25 * i, -5 + 0.25 * j, 0.0] for i in range(41) for j in range(41)], dtype=np.float32)
+    blob = lambda cx, cy: np.array([[np.float32(cx) + np.float32(0.03) * a, np.float32(cy) + np.float32(0.03) * b, np.float32(0.1) * z]
+                                    for z in range(2, 10) for a in (-1, 1) for b in (-1, 1)], dtype=np.float32)
+    mo = oracle.MarkingOracle(marking.shipped_config(euclidean_cluster_extraction_tolerance=0.25, max_markings=1024,
+                                                     max_cluster_points=1 << 16), g, np.zeros((0, 3), np.float32))
+    tbs, tgb = (0, 0, 0.5, 0, 0, 0, 1), (0, 0, 0, 0, 0, 0, 1)
+    s1 = mo.update(np.concatenate([blob(0, 2), blob(-3, 3)]), tbs, tgb)
+    touched, lethal = int((mo.dgraph() < 9999.0).sum()), int(mo.lethal().sum())
+    mo.update(blob(-3, 3), tbs, tgb)
+    s3 = mo.update(blob(-3, 3), tbs, tgb)
+    tag, *vals = tagged["marking"]
+    assert tag == "marking"
+    assert [int(v) for v in vals] == [s1.n_clusters, s1.n_marked, s1.n_alive, touched, lethal, s3.n_cleared, s3.n_alive,
+                                      len(mo.voxels())]
+    assert s1.n_marked == 2 and s3.n_cleared == 1 and s3.n_alive == 1
