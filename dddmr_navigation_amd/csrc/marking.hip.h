@@ -82,6 +82,18 @@ __device__ __forceinline__ void grid_for_each(const PointGrid& g, float qx, floa
         if (f(g.sorted[k])) return;
     }
 }
+// The same walk with the 64 lanes of a wave striding each row's run (one query per wave).
+template <class F>
+__device__ __forceinline__ void grid_for_each_wave(const PointGrid& g, float qx, float qy, float qz, float r, int lane, F&& f) {
+  const int x0 = grid_cx(g, qx - r), x1 = grid_cx(g, qx + r);
+  const int y0 = grid_cy(g, qy - r), y1 = grid_cy(g, qy + r);
+  const int z0 = grid_cz(g, qz - r), z1 = grid_cz(g, qz + r);
+  for (int cz = z0; cz <= z1; ++cz)
+    for (int cy = y0; cy <= y1; ++cy) {
+      const uint32_t b = g.cell_start[(cz * g.ny + cy) * g.nx + x0], e = g.cell_start[(cz * g.ny + cy) * g.nx + x1 + 1];
+      for (uint32_t k = b + (uint32_t)lane; k < e; k += 64) f(g.sorted[k]);
+    }
+}
 // pcl::KdTreeFLANN::radiusSearch count with the squared radius already cast to float
 __device__ __forceinline__ int grid_radius_count(const PointGrid& g, float qx, float qy, float qz, float r, float r2, int stop_at) {
   int cnt = 0;
@@ -111,10 +123,12 @@ struct MarkParams {
   uint32_t pool_cap;
   uint32_t n_ground;
   uint32_t seq;                // update sequence number
+  uint32_t n_alive_prev;       // entries of MarkStore::alive_list
 };
 
 struct MarkCounters {         // device counters of one update (copied back for dddmr_marking_stats)
   uint32_t n_clusters, n_marked, n_in_window, n_cleared, n_alive, pool_used, overflow, n_groups2, n_groups3, n_clusters_kept;
+  uint32_t n_removed, pad;
 };
 
 // isinLidarObservation (:682-746).  The reference builds a rotation that turns the x axis onto the viewing
@@ -170,6 +184,9 @@ struct MarkStore {            // the persistent store (device pointers)
   uint32_t* pts_n;            // [table]
   uint32_t* removed_seq;      // [table] update that cleared the slot
   unsigned long long* owner;  // [table] priority of the cluster that takes the slot in this update (0 = none)
+  uint32_t* alive_list;       // [table] slots alive at the end of the last update (what selfClear walks)
+  uint32_t* removed_list;     // [table] slots this update's selfClear removed
+  uint32_t* fov_flag;         // [table] per alive_list entry: 1 = inside window and sensor view (needs the ray test)
   float4* pool;               // generator points
   double* dgraph;             // [n_ground + 1]
   uint8_t* lethal;            // [n_ground + 1]
@@ -178,17 +195,34 @@ struct MarkStore {            // the persistent store (device pointers)
 // ---------------------------------------------------------------------------------------------
 // selfClear: one wave per store slot
 // ---------------------------------------------------------------------------------------------
+// Window + field-of-view test of every stored marking, one LANE each (the double asin / atan2 / cos of
+// isinLidarObservation cost a whole wave as much as a lane).
+__global__ __launch_bounds__(256) void k_mk_fov(MarkParams k, MarkStore s, MarkCounters* __restrict__ cnt) {
+  const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+  if (w >= k.n_alive_prev) return;
+  const uint32_t slot = s.alive_list[w];
+  uint32_t flag = 0;
+  if (s.alive[slot]) {
+    int x, y, z;
+    voxel_unkey(s.keys[slot], &x, &y, &z);
+    // map iteration lower_bound(min) .. lower_bound(max): keys in [min, max) on every axis (:487-516)
+    if (!(x < k.wx0 || x >= k.wx1 || y < k.wy0 || y >= k.wy1 || z < k.wz0 || z >= k.wz1)) {
+      atomicAdd(&cnt->n_in_window, 1u);
+      const float px = (float)(x * k.res), py = (float)(y * k.res), pz = (float)(z * k.hres);
+      flag = in_lidar_observation(k, px, py, pz) ? 1u : 0u;         // outside the sensor's view: stays (:531-540)
+    }
+  }
+  s.fov_flag[w] = flag;
+}
+
 __global__ __launch_bounds__(256) void k_mk_clear(MarkParams k, MarkStore s, PointGrid prev, MarkCounters* __restrict__ cnt) {
-  const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (slot > k.table_mask || !s.alive[slot]) return;
+  if (w >= k.n_alive_prev || !s.fov_flag[w]) return;
+  const uint32_t slot = s.alive_list[w];
   int x, y, z;
   voxel_unkey(s.keys[slot], &x, &y, &z);
-  // map iteration lower_bound(min) .. lower_bound(max): keys in [min, max) on every axis (:487-516)
-  if (x < k.wx0 || x >= k.wx1 || y < k.wy0 || y >= k.wy1 || z < k.wz0 || z >= k.wz1) return;
-  if (lane == 0) atomicAdd(&cnt->n_in_window, 1u);
   const float px = (float)(x * k.res), py = (float)(y * k.res), pz = (float)(z * k.hres);
-  if (!in_lidar_observation(k, px, py, pz)) return;                 // outside the sensor's view: stays (:531-540)
   const bool observation_clear = !(k.n_prev > 5);
   bool blocked = false;
   if (!observation_clear) {
@@ -234,21 +268,23 @@ __global__ __launch_bounds__(256) void k_mk_clear(MarkParams k, MarkStore s, Poi
     s.alive[slot] = 0;
     s.removed_seq[slot] = k.seq;
     atomicAdd(&cnt->n_cleared, 1u);
+    s.removed_list[atomicAdd(&cnt->n_removed, 1u)] = slot;
   }
 }
 
 // removePCPtr's loop over nodes_of_min_distance_, recomputed from the marking's generator points: every ground node
 // within inflation_radius (3-D) of one gets clearValue(node, 9999.0); erased from the lethal set where the xy distance
 // is within the inscribed radius.  One wave per slot cleared in this update.
-__global__ __launch_bounds__(256) void k_mk_unmark(MarkParams k, MarkStore s, PointGrid ground) {
-  const uint32_t slot = blockIdx.x * 4 + (threadIdx.x >> 6);
+__global__ __launch_bounds__(256) void k_mk_unmark(MarkParams k, MarkStore s, PointGrid ground, const MarkCounters* __restrict__ cnt) {
+  const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (slot > k.table_mask || s.removed_seq[slot] != k.seq || s.alive[slot]) return;
+  if (w >= cnt->n_removed) return;
+  const uint32_t slot = s.removed_list[w];
   const uint32_t ofs = s.pts_ofs[slot], n = s.pts_n[slot];
   const float r = (float)k.inflation, r2 = static_cast<float>(k.inflation * k.inflation);
-  for (uint32_t i = lane; i < n; i += 64) {
+  for (uint32_t i = 0; i < n; ++i) {                                // (a marking has a handful of generator points)
     const float4 p = s.pool[ofs + i];
-    grid_for_each(ground, p.x, p.y, p.z, r + 1e-4f, [&](const float4 g) {
+    grid_for_each_wave(ground, p.x, p.y, p.z, r + 1e-4f, lane, [&](const float4 g) {
       if (l2_simple(g.x, g.y, g.z, p.x, p.y, p.z) < r2) {
         const int node = __float_as_int(g.w);
         const float dx = p.x - g.x, dy = p.y - g.y;
@@ -256,7 +292,6 @@ __global__ __launch_bounds__(256) void k_mk_unmark(MarkParams k, MarkStore s, Po
         s.dgraph[node] = 9999.0;
         if (d <= k.inscribed) s.lethal[node] = 0;
       }
-      return false;
     });
   }
 }
@@ -499,17 +534,18 @@ __global__ __launch_bounds__(64) void k_mk_commit(MarkParams k, const MarkCounte
 }
 // one lane per generator point of an accepted cluster: copy into the pool (winner of its voxel) and
 // computeMinDistanceFromObstacle2GroundNodes + DynamicGraph::setValue + lethal_map_ (cluster_marking.cpp:66-123)
-__global__ __launch_bounds__(64) void k_mk_dgraph(MarkParams k, const uint32_t* __restrict__ n_gen, const float4* __restrict__ gen,
-                                                  ClusterArrays c, const uint32_t* __restrict__ pool_ofs, MarkStore s,
-                                                  PointGrid ground) {
-  const uint32_t h = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void k_mk_dgraph(MarkParams k, const uint32_t* __restrict__ n_gen, const float4* __restrict__ gen,
+                                                   ClusterArrays c, const uint32_t* __restrict__ pool_ofs, MarkStore s,
+                                                   PointGrid ground) {
+  const uint32_t h = blockIdx.x * 4 + (threadIdx.x >> 6);          // one WAVE per generator point, lanes over ground nodes
+  const int lane = threadIdx.x & 63;
   if (h >= *n_gen) return;
   const float4 p = gen[h];
   const uint32_t ci = (uint32_t)__float_as_int(p.w);
   const uint32_t po = pool_ofs[ci];
-  if (po != 0xFFFFFFFFu) s.pool[po + (h - c.gen_first[ci])] = make_float4(p.x, p.y, p.z, 0.f);
+  if (lane == 0 && po != 0xFFFFFFFFu) s.pool[po + (h - c.gen_first[ci])] = make_float4(p.x, p.y, p.z, 0.f);
   const float r = (float)k.inflation, r2 = static_cast<float>(k.inflation * k.inflation);
-  grid_for_each(ground, p.x, p.y, p.z, r + 1e-4f, [&](const float4 g) {
+  grid_for_each_wave(ground, p.x, p.y, p.z, r + 1e-4f, lane, [&](const float4 g) {
     if (l2_simple(g.x, g.y, g.z, p.x, p.y, p.z) < r2) {
       const int node = __float_as_int(g.w);
       const float dx = p.x - g.x, dy = p.y - g.y;
@@ -518,14 +554,13 @@ __global__ __launch_bounds__(64) void k_mk_dgraph(MarkParams k, const uint32_t* 
       atomicMin(reinterpret_cast<unsigned long long*>(s.dgraph) + node, (unsigned long long)__double_as_longlong((double)d));
       if (d <= k.inscribed) s.lethal[node] = 1;
     }
-    return false;
   });
 }
 __global__ __launch_bounds__(256) void k_mk_finish(MarkParams k, MarkStore s, MarkCounters* __restrict__ cnt) {
   const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
   if (slot > k.table_mask) return;
   s.owner[slot] = 0ull;
-  if (s.alive[slot]) atomicAdd(&cnt->n_alive, 1u);
+  if (s.alive[slot]) s.alive_list[atomicAdd(&cnt->n_alive, 1u)] = slot;      // next update's selfClear walks this list
 }
 // pool compaction: generator points of the alive markings move to the front of the other pool buffer
 __global__ __launch_bounds__(256) void k_mk_compact_sizes(uint32_t table, MarkStore s, uint32_t* __restrict__ sizes) {

@@ -24,7 +24,7 @@ struct MarkingState {
   float4* obs_copy[2] = {nullptr, nullptr};
   MarkStore store{};
   float4* pool_alt = nullptr;
-  uint32_t pool_used_host = 0;
+  uint32_t pool_used_host = 0, n_alive_host = 0;
   // scratch of one update (sized for max_obs)
   uint2* gslot = nullptr;
   uint32_t* parent = nullptr;
@@ -50,7 +50,8 @@ void free_grid(GridBuf& b) {
 void marking_free(MarkingState* m) {
   if (!m) return;
   void* p[] = {m->ground_pts, m->map_pts, m->obs_copy[0], m->obs_copy[1], m->store.keys, m->store.alive, m->store.pts_ofs,
-               m->store.pts_n, m->store.removed_seq, m->store.owner, m->store.pool, m->pool_alt, m->store.dgraph, m->store.lethal,
+               m->store.pts_n, m->store.removed_seq, m->store.owner, m->store.alive_list, m->store.removed_list, m->store.fov_flag,
+               m->store.pool, m->pool_alt, m->store.dgraph, m->store.lethal,
                m->gslot, m->parent, m->keys_a, m->keys_b, m->keys1, m->vals_a, m->vals_b, m->flags, m->incl, m->cid_incl, m->ds,
                m->proj, m->gen, m->ds_first, m->pool_ofs, m->compact_sizes, m->compact_ofs, m->cl.start, m->cl.size, m->cl.centroid,
                m->cl.state, m->cl.ds_count, m->cl.gen_first, m->cl.gen_count, m->cl.slot, m->cl.vkey, m->counters, m->n_groups,
@@ -233,6 +234,9 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     HIPCHK(ctx, hipMalloc(&s.pts_n, (size_t)table * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&s.removed_seq, (size_t)table * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&s.owner, (size_t)table * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMalloc(&s.alive_list, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&s.removed_list, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&s.fov_flag, (size_t)table * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&s.pool, (size_t)m->pool_cap * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&m->pool_alt, (size_t)m->pool_cap * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&s.dgraph, ((size_t)n_ground + 1) * sizeof(double)));
@@ -303,6 +307,7 @@ int marking_reset_locked(dddmr_rollout_ctx* ctx) {
                      m->cfg.max_obstacle_distance);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   m->pool_used_host = 0;
+  m->n_alive_host = 0;
   // (pcl_msg_gbl_ is untouched by resetdGraph: the previous observation stays)
   return DDDMR_OK;
 }
@@ -373,6 +378,7 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
   k.table_mask = m->table - 1;
   k.pool_cap = m->pool_cap;
   k.n_ground = m->n_ground;
+  k.n_alive_prev = m->n_alive_host;
   k.seq = ++m->seq;
   if (k.seq == 0) k.seq = m->seq = 1;
 
@@ -395,8 +401,11 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
   // ---- selfClear against the previous observation ----
   const PointGrid empty_grid = m->obs[0].g;
   const PointGrid& prev_grid = m->prev >= 0 ? m->obs[m->prev].g : empty_grid;
-  hipLaunchKernelGGL(k_mk_clear, dim3((m->table + 3) / 4), dim3(256), 0, st, k, s, prev_grid, m->counters);
-  hipLaunchKernelGGL(k_mk_unmark, dim3((m->table + 3) / 4), dim3(256), 0, st, k, s, m->ground.g);
+  if (m->n_alive_host > 0) {
+    hipLaunchKernelGGL(k_mk_fov, dim3((m->n_alive_host + 255) / 256), dim3(256), 0, st, k, s, m->counters);
+    hipLaunchKernelGGL(k_mk_clear, dim3((m->n_alive_host + 3) / 4), dim3(256), 0, st, k, s, prev_grid, m->counters);
+    hipLaunchKernelGGL(k_mk_unmark, dim3((m->n_alive_host + 3) / 4), dim3(256), 0, st, k, s, m->ground.g, m->counters);
+  }
   HIPCHK(ctx, hipEventRecord(m->e1, st));
 
   // ---- selfMark of this observation ----
@@ -459,7 +468,7 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
     // addPCPtr
     hipLaunchKernelGGL(k_mk_slots, cb, dim3(64), 0, st, k, m->counters, m->cl, s, m->counters);
     hipLaunchKernelGGL(k_mk_commit, cb, dim3(64), 0, st, k, m->counters, m->cl, s, m->counters, m->pool_ofs);
-    hipLaunchKernelGGL(k_mk_dgraph, cb, dim3(64), 0, st, k, m->n_groups + 1, m->gen, m->cl, m->pool_ofs, s, m->ground.g);
+    hipLaunchKernelGGL(k_mk_dgraph, dim3((n_obs + 3) / 4), dim3(256), 0, st, k, m->n_groups + 1, m->gen, m->cl, m->pool_ofs, s, m->ground.g);
     m->prev = cur;                                                               // pcl_msg_gbl_ of this selfMark
     m->n_prev = n_obs;
   }
@@ -470,6 +479,7 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
   HIPCHK(ctx, hipStreamSynchronize(st));
   HIPCHK(ctx, hipGetLastError());
   m->pool_used_host = out.pool_used;
+  m->n_alive_host = out.n_alive;
   if (stats) {
     stats->n_observation = n_obs > 5 ? n_obs : 0;
     stats->n_clusters = out.n_clusters_kept;

@@ -246,6 +246,7 @@ struct dddmr_rollout_ctx {
   float cell_size = 0.25f;
   bool cell_forced = false;   // DDDMR_CELL given: no automatic growth on big shards
   int tile_override = 0;
+  int rt_override = 0;        // DDDMR_RT: trajectories per rollout workgroup
   int threads_override = 0;   // DDDMR_THREADS: force the 256- or 512-lane k_score
   int n_cu = 256;   // compute units of the device
   int timing = 1;   // DDDMR_TIMING: 0 no HIP events, 1 around k_score (score_ms), 2 also around the whole tick
@@ -494,6 +495,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     if (v > 0.01f && v < 10.f) { ctx->cell_size = v; ctx->cell_forced = true; }
   }
   if (const char* e = std::getenv("DDDMR_TILE")) ctx->tile_override = std::atoi(e);
+  if (const char* e = std::getenv("DDDMR_RT")) ctx->rt_override = std::atoi(e);
   if (const char* e = std::getenv("DDDMR_THREADS")) ctx->threads_override = std::atoi(e) == 512 ? 512 : 256;
   if (const char* e = std::getenv("DDDMR_TIMING")) ctx->timing = std::atoi(e);
   if (const char* e = std::getenv("DDDMR_TIMING_EVERY")) ctx->timing_every = std::max(1, std::atoi(e));
@@ -1077,6 +1079,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     // 64 trajectories per workgroup 44 us, 32: 56 us, 16: 86 us), and on small ones ~128
     // workgroups are the sweet spot (C2: 16 per workgroup 14.4 us, 32: 12.1 us, 64: 13.2 us).
     int rt = std::min(std::max((k.n_local + 127) / 128, 4), 64);
+    if (ctx->rt_override > 0) rt = std::min(ctx->rt_override, 64);
     while (rt > 1 && rollout_lds_bytes(rt, s_tick) > (size_t)128 * 1024) --rt;
     k.rt = rt;
   }
