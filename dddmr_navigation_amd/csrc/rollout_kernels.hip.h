@@ -860,6 +860,28 @@ __device__ __forceinline__ void pose_translation(const DevTick& k, float2 bxy, d
   for (int i = 0; i < 3; ++i) T[i] = k.R[3 * i + 0] * (double)bxy.x + k.R[3 * i + 1] * (double)bxy.y + k.t[i];
 }
 
+// OBB record words [3..14]: the cuboid's vertices blb, brb, blt, flb as phase D1 left them -> axes (x: blb->flb,
+// y: blb->brb, z: blb->blt, collision_model.cpp:97-110) and half extents (:112-115), in place.
+__device__ __forceinline__ void obb_axes_in_place(float* r) {
+  float v[4][3];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) { v[a][0] = r[3 + 3 * a]; v[a][1] = r[4 + 3 * a]; v[a][2] = r[5 + 3 * a]; }
+  const int vi[3] = {3, 1, 2};
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float ex = fsub(v[vi[a]][0], v[0][0]), ey = fsub(v[vi[a]][1], v[0][1]), ez = fsub(v[vi[a]][2], v[0][2]);
+    const float len = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
+    // The reference divides in double, (float)((double)e / (2. * h)) with h = (double)len / 2.:
+    // 2h == len exactly, and rounding a double quotient of two floats to float equals
+    // the correctly rounded float division (53 >= 2*24 + 2 bits: double rounding is
+    // innocuous for division) -- so the IEEE float divide gives the same bits for less.
+    r[12 + a] = len * 0.5f;                  // len/2 is exact in float
+    r[3 + 3 * a + 0] = ex / len;
+    r[3 + 3 * a + 1] = ey / len;
+    r[3 + 3 * a + 2] = ez / len;
+  }
+}
+
 // Winner decode (local_planner.cpp:447-480), run by ONE wave once every k_score workgroup has filed its keys:
 // either wave 0 of the workgroup that drew the last ticket (small shards: no extra launch) or k_finalize.
 //
@@ -1097,19 +1119,14 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
       }
       float* r = rec + (size_t)q * rec_words;
       r[0] = ccx / 8.f; r[1] = ccy / 8.f; r[2] = ccz / 8.f;
-      const int vi[3] = {3, 1, 2};
+      // The box axes and half extents (three square roots, nine divisions) are only needed by pairs that find
+      // candidate points at all -- a minority: the four vertices they derive from are parked in the record and
+      // phase D2 finishes the record of a pair once it knows the pair has work (obb_axes_in_place).
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float ex = fsub(v[vi[a]][0], v[0][0]), ey = fsub(v[vi[a]][1], v[0][1]), ez = fsub(v[vi[a]][2], v[0][2]);
-        const float len = sqrtf(dot3(ex, ey, ez, ex, ey, ez));
-        // The reference divides in double, (float)((double)e / (2. * h)) with h = (double)len / 2.:
-        // 2h == len exactly, and rounding a double quotient of two floats to float equals
-        // the correctly rounded float division (53 >= 2*24 + 2 bits: double rounding is
-        // innocuous for division) -- so the IEEE float divide gives the same bits for less.
-        r[12 + a] = len * 0.5f;                  // len/2 is exact in float
-        r[3 + 3 * a + 0] = ex / len;
-        r[3 + 3 * a + 1] = ey / len;
-        r[3 + 3 * a + 2] = ez / len;
+      for (int a = 0; a < 4; ++a) {
+        r[3 + 3 * a + 0] = v[a][0];
+        r[3 + 3 * a + 1] = v[a][1];
+        r[3 + 3 * a + 2] = v[a][2];
       }
       // candidate cells: cuboid AABB clipped to the 1 m search ball's AABB
       const float lox = fmaxf(mnx, px - 1.0f), hix = fminf(mxx, px + 1.0f);
@@ -1231,6 +1248,7 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
       }
       const unsigned long long ex = carry + wofs + incl - cnt;
       if (cnt) {
+        obb_axes_in_place(rec + (size_t)q * rec_words);   // this pair has candidate points: finish its OBB record
         // items of this pair towards its trajectory's total (-> first item of every trajectory below)
         atomicAdd(&t_item0[reinterpret_cast<const int*>(rec + (size_t)q * rec_words)[17] & 0xFFFF], (uint32_t)cnt);
         uint32_t ci = (uint32_t)(ex >> 32), itn = (uint32_t)ex;
