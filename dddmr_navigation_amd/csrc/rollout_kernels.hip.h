@@ -111,6 +111,7 @@ struct DevTick {
   int box_fast;      // the cuboid is a body-frame box in the reference's vertex order (host-checked)
   int rec_pose;      // OBB records carry the pose (some pair may need the 1 m radius test, or min-max critic)
   int final_kernel;  // 1: the winner is decoded by k_finalize after k_score (multi-round shards), 0: by k_score's last workgroup
+  int probe;         // 1: the collision walk starts with a probe round (pays when most trajectories collide)
   uint32_t seq;      // tick sequence number echoed into DevResult::seq
   float axes_inl[kInlineAxes];
 };
@@ -131,7 +132,7 @@ struct DevResult {    // written by the last k_score workgroup into host-mapped 
   uint32_t n_binned;
   uint32_t overflow;  // 1 if a trajectory needed more than max_steps
   uint32_t seq;       // tick sequence number, stored LAST: the host may poll it instead of a stream sync
-  uint32_t pad;
+  uint32_t n_collided; // trajectories of the shard the collision critics rejected (feedback for DevTick::probe)
 };
 
 __host__ __device__ inline int64_t pack_key(double cost, uint32_t gidx) {
@@ -346,6 +347,7 @@ __global__ __launch_bounds__(256) void k_bin_reset(DevTick k, uint32_t* __restri
   if (threadIdx.x == 0) {
     best_key[0] = kKeyNone;
     best_key[1] = kKeyNone;
+    best_key[2] = 0;
     *overflow = 0;
   }
   scan_cells(k, cell_count, cell_start, wave_sum, &carry_s);
@@ -739,6 +741,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_count(DevTick k, const f
       *ticket = 0;            // next tick
       best_key[0] = kKeyNone;
       best_key[1] = kKeyNone;
+      best_key[2] = 0;            // collided-trajectory count of the tick
       *overflow = 0;
     }
   }
@@ -927,7 +930,12 @@ __device__ __forceinline__ void decode_winner(const DevTick& k, const int lane, 
     r.n_binned = cell_start[k.n_cells];
     r.overflow = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     r.seq = 0;
-    r.pad = 0;
+    {
+      // sampled share of collided trajectories, scaled to the shard
+      const unsigned long long w2 = (unsigned long long)__hip_atomic_load(best_key + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long sampled = w2 >> 32, collided = w2 & 0xFFFFFFFFull;
+      r.n_collided = sampled ? (uint32_t)(collided * (unsigned long long)k.n_local / sampled) : 0u;
+    }
     *result = r;
     if (words_out) {
       // multi-rank context: this shard's (cost bits, -index) slot of the all-reduce that follows on
@@ -944,7 +952,9 @@ __device__ __forceinline__ void decode_winner(const DevTick& k, const int lane, 
 // kLean: the common critic stack -- no min-max critic and no pair that needs the 1 m radius test
 // (the cuboid lies inside the search ball) -- as compile-time facts: the walk loses its radius /
 // min-max code and the records their optional words.
-template <int kScoreThreads, bool kLean>
+// kProbe: the collision walk starts with a probe round (compile-time: as a run-time flag it cost the walk its
+// schedule -- 121 -> 107 VGPRs and +10 % time).
+template <int kScoreThreads, bool kLean, bool kProbe>
 __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_WPE : DDDMR_SCORE_WPE_256) void k_score(
     DevTick k, const TrajInfo* __restrict__ info, const double2* __restrict__ st_sc, const float2* __restrict__ st_xy,
     const float4* __restrict__ plan_xyz, const uint32_t* __restrict__ cell_start,
@@ -1341,7 +1351,7 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
       }
       return lo;
     };
-    const int n_rounds = total > (uint32_t)kScoreThreads ? 2 : 1;
+    const int n_rounds = (kProbe && total > (uint32_t)kScoreThreads) ? 2 : 1;
     for (int round = 0; round < n_rounds; ++round) {
       if (tid < 64) {                               // exclusive prefix of the undecided trajectories' item counts
         uint32_t cnt = 0;
@@ -1586,9 +1596,33 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
       key = (int64_t)kk;                                   // lane 0: minimum of lanes 0..15
       cbits = (int64_t)cc;
     }
+    // Same-address device-scope atomics serialise (~4 ns each) and the workgroups of a balanced launch all arrive
+    // here together: a workgroup first LOOKS at the running minima (plain device-scope loads, served in parallel)
+    // and only issues an atomicMin for a word it can still lower.  The minima only ever decrease, so a stale
+    // (larger) value can cause a superfluous atomic, never a missing one.
+    // (Shards that run as ONE round keep the unconditional pair: there the look is a ~1.5 us round trip on the
+    // launch's critical tail -- C2 k_score 33.6 vs 35.1 us -- while multi-round shards gain: C3 126.5 -> 122 us.)
     if (tid == 0 && key != kKeyNone) {
-      atomicMin((long long*)best_key, (long long)key);
-      atomicMin((long long*)best_key + 1, (long long)cbits);
+      if (k.final_kernel) {
+        const long long cur_k = (long long)__hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long cur_c = (long long)__hip_atomic_load(best_key + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((long long)key < cur_k) atomicMin((long long*)best_key, (long long)key);
+        if ((long long)cbits < cur_c) atomicMin((long long*)best_key + 1, (long long)cbits);
+      } else {
+        atomicMin((long long*)best_key, (long long)key);
+        atomicMin((long long*)best_key + 1, (long long)cbits);
+      }
+    }
+    // How many trajectories the collision critics rejected -- a SAMPLE (every 16th workgroup; tiles are dealt as
+    // representative mixes): the next tick's walk starts with a probe round only when most do (the probe settles
+    // colliding trajectories early and is pure overhead otherwise).  Word 2 counts the sampled collided
+    // trajectories in its low half and the sampled trajectories in its high half.
+    if ((blockIdx.x & 15u) == 0u) {
+      const bool gen = tid < nt && head[tid].steps > 0;
+      const bool coll = gen && cloud_ok && ((need_box && head[tid].hit_box) || (need_mm && head[tid].hit_mm));
+      const unsigned long long cm = __ballot(coll), gm = __ballot(gen);
+      if (tid == 0 && gm)
+        atomicAdd((unsigned long long*)best_key + 2, ((unsigned long long)__popcll(gm) << 32) | (unsigned long long)__popcll(cm));
     }
   }
   // ---- winner decode ----
@@ -1633,7 +1667,7 @@ __global__ void k_empty_result(DevTick k, const uint32_t* __restrict__ cell_star
   r.n_binned = cell_start[k.n_cells];
   r.overflow = 0;
   r.seq = 0;
-  r.pad = 0;
+  r.n_collided = 0;
   *res = r;
   if (words_out) {
     words_out[0] = kKeyNone;
@@ -1691,7 +1725,7 @@ __global__ void k_resolve(DevTick k, const int64_t* __restrict__ slots, int n_ra
   r.n_binned = local->n_binned;
   r.overflow = local->overflow;
   r.seq = 0;
-  r.pad = 0;
+  r.n_collided = local->n_collided;
   *res = r;
   __threadfence_system();
   __hip_atomic_store(&res->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
