@@ -16,10 +16,20 @@ src = os.path.join(root, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-def short(name):
+def short(name, keep_template=False):
     n = name.split("(")[0]
     n = n.replace("dddmr::", "").replace("void ", "").strip()
-    return n.split("<")[0] if n.startswith("k_") else n
+    return n.split("<")[0] if n.startswith("k_") and not keep_template else n
+
+
+def merged_avg_ns(rows):
+    """calls-weighted average duration per kernel, all template instantiations of a kernel pooled
+    (k_score<..., kProbe=true> runs on the first tick only, the lean instantiation on the rest)"""
+    tot, calls = defaultdict(float), defaultdict(int)
+    for r in rows:
+        tot[short(r["Name"])] += float(r["TotalDurationNs"])
+        calls[short(r["Name"])] += int(r["Calls"])
+    return {k: tot[k] / calls[k] for k in tot if calls[k]}
 
 # ---- kernel stats ----
 rows = []
@@ -31,7 +41,7 @@ if rows:
         w = csv.writer(fo)
         w.writerow(["kernel", "calls", "total_ns", "avg_ns", "min_ns", "max_ns", "pct"])
         for r in rows:
-            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]])
+            w.writerow([short(r["Name"], keep_template=True), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["Percentage"]])
     print(open(stats_out).read())
 
 # ---- per-kernel trace: VGPR, LDS, grid ----
@@ -78,7 +88,7 @@ def update(path, key, value):
 
 # rocprofv3's average durations (ms) of the tick's kernels for this workload
 if rows:
-    avg = {short(r["Name"]) + "_ms": round(float(r["AverageNs"]) * 1e-6, 6) for r in rows if short(r["Name"]).startswith("k_")}
+    avg = {k + "_ms": round(v * 1e-6, 6) for k, v in merged_avg_ns(rows).items() if k.startswith("k_")}
     avg["source"] = f"profiles/{tag}_kernel_stats.csv"
     update(os.path.join(dst, f"{rnd}_kernel_avg.json"), workload, avg)
     print("kernel averages", avg)
@@ -87,7 +97,7 @@ if rows:
 # ACTIVE_INST_ANY ~ WAVE_CYCLES.  VALU busy = VALU issue cycles over the SIMD-cycles of the launch
 # (1024 SIMDs x rocprofv3's average duration x 2.4 GHz peak clock: a lower bound of the share).
 if "SQ_WAVE_CYCLES" in ks and rows:
-    dur_ns = next((float(r["AverageNs"]) for r in rows if short(r["Name"]) == "k_score"), None)
+    dur_ns = merged_avg_ns(rows).get("k_score")
     lim = {
         "waves_waiting_frac": round(ks["SQ_WAIT_ANY"] / ks["SQ_WAVE_CYCLES"], 4),
         "issue_stall_frac": round(ks["SQ_WAIT_INST_ANY"] / ks["SQ_WAVE_CYCLES"], 4),
