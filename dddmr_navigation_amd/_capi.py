@@ -205,6 +205,7 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_marking_get_dgraph",
     "dddmr_rollout_marking_get_lethal",
     "dddmr_rollout_stream_ceiling",
+    "dddmr_rollout_selftest_sincos",
     "dddmr_rollout_last_error",
     "dddmr_rollout_version",
 )
@@ -298,6 +299,8 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_marking_get_lethal.restype = C.c_int
     lib.dddmr_rollout_stream_ceiling.argtypes = [ctx_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.dddmr_rollout_stream_ceiling.restype = C.c_int
+    lib.dddmr_rollout_selftest_sincos.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    lib.dddmr_rollout_selftest_sincos.restype = C.c_int
     lib.dddmr_rollout_last_error.argtypes = [ctx_p]
     lib.dddmr_rollout_last_error.restype = C.c_char_p
     lib.dddmr_rollout_version.argtypes = []

@@ -1092,8 +1092,23 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
     // 1024-lane workgroup costs ~12 ns, which is what bounds the launch on big shards (C4:
     // 64 trajectories per workgroup 44 us, 32: 56 us, 16: 86 us), and on small ones ~128
     // workgroups are the sweet spot (C2: 16 per workgroup 14.4 us, 32: 12.1 us, 64: 13.2 us).
-    int rt = std::min(std::max((k.n_local + 127) / 128, 4), 64);
-    if (ctx->rt_override > 0) rt = std::min(ctx->rt_override, 64);
+    // Round 2: the launch's dynamic LDS (the rollout rows, 16 bytes per pair) is allocated by EVERY workgroup of
+    // k_bin_count, and a CU holds two 1024-lane workgroups at most (wave slots).  Rows sized for two per CU
+    // (<= 74 KB beside ~6 KB of static LDS) keep the whole launch resident in one round at C3 (the rollout
+    // workgroups used to start in two rounds: k_bin_count 28 -> ~18 us).  Within a quarter of that cap the row count
+    // that fills phase B's 1024-lane passes best wins (C3: 50 x 81 pairs = 3.96 passes, C4: 80 x 51 = 3.98).
+    const int s1 = s_tick + 1;
+    const int rt_lds = (int)std::min<size_t>((size_t)kRolloutMax, ((size_t)74 * 1024 - 16) / ((size_t)s1 * 16));
+    int rt = std::min(std::max((k.n_local + 127) / 128, 4), std::max(rt_lds, 1));
+    if (rt == rt_lds && rt > 4) {
+      double best_fill = 0.0;
+      for (int c = rt_lds; c >= rt_lds - rt_lds / 4; --c) {
+        const int items = c * s1;
+        const double fill = (double)items / (double)((items + kBinThreads - 1) / kBinThreads * kBinThreads);
+        if (fill > best_fill + 1e-9) { best_fill = fill; rt = c; }
+      }
+    }
+    if (ctx->rt_override > 0) rt = std::min(ctx->rt_override, kRolloutMax);
     while (rt > 1 && rollout_lds_bytes(rt, s_tick) > (size_t)128 * 1024) --rt;
     k.rt = rt;
   }
@@ -1423,6 +1438,30 @@ int dddmr_rollout_comm_destroy(dddmr_rollout_ctx* ctx) {
 
 // Stream ceiling of this GPU ("a measured stream-copy ceiling on the same GPU ... both
 // denominators"): `bytes` per buffer (>= 1 GiB defeats the 256 MB of MALL), `reps` launches each.
+int dddmr_rollout_selftest_sincos(dddmr_rollout_ctx* ctx, const double* angles, size_t n, double* sin_out,
+                                  double* cos_out) {
+  if (!ctx || !angles || !sin_out || !cos_out || n == 0 || n > ((size_t)1 << 24)) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "selftest_sincos while a tick_begin is pending");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  double* buf = nullptr;
+  HIPCHK(ctx, hipMalloc(&buf, 3 * n * sizeof(double)));
+  int rc = DDDMR_OK;
+  auto run = [&]() -> int {
+    HIPCHK(ctx, hipMemcpyAsync(buf, angles, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_selftest_sincos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, buf, (int)n,
+                       buf + n, buf + 2 * n);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(sin_out, buf + n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(cos_out, buf + 2 * n, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return DDDMR_OK;
+  };
+  rc = run();
+  (void)hipFree(buf);
+  return rc;
+}
+
 int dddmr_rollout_stream_ceiling(dddmr_rollout_ctx* ctx, size_t bytes, int32_t reps, double* copy_gbps,
                                  double* read_gbps) {
   if (!ctx || !copy_gbps || !read_gbps || reps <= 0 || bytes < (1u << 20)) return DDDMR_ERR_BAD_ARG;

@@ -48,6 +48,7 @@ namespace dddmr {
 // the shard fits one round of resident workgroups (C2); 256 lanes keep more, smaller
 // workgroups in flight and win on big batches (C3, C4).
 constexpr int kBinPer = 4;            // points per lane and pass of a binning workgroup
+constexpr int kRolloutMax = 128;      // trajectories per rollout workgroup (phase A: a lane each, C: two), at most
 constexpr int kBinThreads = 1024;     // k_bin_count workgroup (its last workgroup scans 4096 cells per step)
 constexpr int kMaxTile = 16;          // trajectories per workgroup (upper bound)
 constexpr int kMaxPlan = 512;         // prune-plan poses kept in LDS
@@ -233,8 +234,13 @@ __device__ __forceinline__ double dpp_row_shl(double v) {
 // ranges a heading never has.  fdlibm's algorithm for |x| < 2^20 pi/2: Cody-Waite
 // reduction with pi/2 in 33-bit pieces (118 bits, exact products), then the
 // __kernel_sin / __kernel_cos polynomials on [-pi/4, pi/4] with the reduction's tail;
-// < 0.8 ulp (ocml and glibc: <= 1 ulp), ~50 double operations.  Larger arguments fall
-// back to ocml.
+// < 0.8 ulp (ocml and glibc: <= 1 ulp; tests/test_parity_gpu.py checks it against long-double
+// values through dddmr_rollout_selftest_sincos).  Larger arguments fall back to ocml.
+// Separate multiplies and adds on purpose: the fused form was measured (round 2) and is slower here --
+// v_fma_f64 itself issues at the rate of v_mul_f64 / v_add_f64 (tools/ubench/f64_rate.hip: ~5 cycles per
+// wave-instruction each), but the compiler picks v_fmac_f64, whose addend must sit in VGPRs while
+// v_mul / v_add read the coefficients from SGPR pairs; under k_bin_count's 64-VGPR cap (two 1024-lane
+// workgroups per CU) that spilled 14 registers and phase B went from 14.5 to 24 kilo-cycles.
 __device__ __forceinline__ void sincos_heading(const double x, double* sn, double* cs) {
   if (fabs(x) > 1.0e5) {
     sincos(x, sn, cs);
@@ -242,30 +248,34 @@ __device__ __forceinline__ void sincos_heading(const double x, double* sn, doubl
   }
   const double fn = rint(x * 6.36619772367581382433e-01);
   const int n = (int)fn;
-  double r = x - fn * 1.57079632673412561417e+00;
-  const double t = r;
+#define DDDMR_MADD(a, b, c) ((a) * (b) + (c))
+  const double t = x - fn * 1.57079632673412561417e+00;     // exact product: 33-bit piece x |fn| < 2^20
   double w = fn * 6.07710050630396597660e-11;
-  r = t - w;
+  const double r = t - w;
   w = fn * 2.02226624879595063154e-21 - ((t - r) - w);
   const double y0 = r - w;
   const double y1 = (r - y0) - w;
   const double z = y0 * y0;
   const double v = z * y0;
-  const double ps = 8.33333333332248946124e-03 +
-                    z * (-1.98412698298579493134e-04 +
-                         z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double ps = DDDMR_MADD(z, DDDMR_MADD(z, DDDMR_MADD(z, DDDMR_MADD(z, 1.58969099521155010221e-10,
+                               -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                               -1.98412698298579493134e-04), 8.33333333332248946124e-03);
   const double s = y0 - ((z * (0.5 * y1 - v * ps) - y1) - v * -1.66666666666666324348e-01);
-  const double pc = z * (4.16666666666666019037e-02 +
-                         z * (-1.38888888888741095749e-03 +
-                              z * (2.48015872894767294178e-05 +
-                                   z * (-2.75573143513906633035e-07 +
-                                        z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const double pc = z * DDDMR_MADD(z, DDDMR_MADD(z, DDDMR_MADD(z, DDDMR_MADD(z, DDDMR_MADD(z,
+                                   -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                   -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                   -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+#undef DDDMR_MADD
   const double hz = 0.5 * z;
   const double w2 = 1.0 - hz;
   const double c = w2 + (((1.0 - w2) - hz) + (z * pc - y0 * y1));
-  const int q = n & 3;
-  *sn = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
-  *cs = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+  // quadrant n & 3: 0 (s, c)  1 (c, -s)  2 (-s, -c)  3 (-c, s) -- one swap, then sign bits
+  const bool odd = (n & 1) != 0;
+  const double a = odd ? c : s, b = odd ? s : c;
+  const unsigned long long sa = (unsigned long long)((n >> 1) & 1) << 63;          // sin negative in quadrants 2, 3
+  const unsigned long long sb = (unsigned long long)(((n + 1) >> 1) & 1) << 63;    // cos negative in quadrants 1, 2
+  *sn = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(a) ^ sa));
+  *cs = __longlong_as_double((long long)((unsigned long long)__double_as_longlong(b) ^ sb));
 }
 
 // cos/sin(M_PI_2 + theta) in double from sin/cos(theta) (omni_simple...cpp:501-502).  The
@@ -280,6 +290,16 @@ __device__ __forceinline__ void sincos_quarter_ahead(const double ang, const dou
   const double e = 6.123233995736766e-17 + err;
   *c2 = -sn + e * cs;
   *s2 = cs + e * sn;
+}
+
+// dddmr_rollout_selftest_sincos: the routine above, one angle per lane
+__global__ void k_selftest_sincos(const double* __restrict__ ang, int n, double* __restrict__ sn, double* __restrict__ cs) {
+  const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (i >= n) return;
+  double s, c;
+  sincos_heading(ang[i], &s, &c);
+  sn[i] = s;
+  cs[i] = c;
 }
 
 // ---------------------------------------------------------------------------
@@ -398,7 +418,11 @@ __device__ unsigned long long g_stamps[16384 * kStampSlots];
 __device__ unsigned long long g_rstamps[4096 * 8];
 #define DDDMR_RSTAMP(i)                                                                        \
   do {                                                                                         \
-    if (threadIdx.x == 0 && blockIdx.x < 4096) g_rstamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {                                                 \
+      g_rstamps[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();                            \
+      if ((i) == 0) g_rstamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();            \
+      if ((i) == 3) g_rstamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();            \
+    }                                                                                            \
   } while (0)
 #else
 #define DDDMR_STAMP(i) do { } while (0)
@@ -414,7 +438,7 @@ struct TrajInfo {      // per trajectory, 32 bytes
 };
 
 __host__ __device__ inline size_t rollout_lds_bytes(int rt, int max_steps) {
-  return (size_t)rt * (size_t)(max_steps + 1) * (4 + 16) + 16;   // theta + increment rows
+  return (size_t)rt * (size_t)(max_steps + 1) * 16 + 16;   // one 16-byte slot per (trajectory, step): theta, then the increment
 }
 
 template <int kThreads>
@@ -424,11 +448,14 @@ __device__ __forceinline__ void rollout_block(const DevTick& k, const int block,
                                               unsigned char* roll_lds) {
   const int S1 = k.max_steps + 1;
   const int rt = k.rt;
-  double2* inc = reinterpret_cast<double2*>(roll_lds);                   // [rt][S1]
-  float* th = reinterpret_cast<float*>(inc + (size_t)rt * S1);           // [rt][S1]
-  __shared__ int steps_s[64];
-  __shared__ float vel_s[64][3];
-  __shared__ double dt_s[64];
+  // [rt][S1] slots of 16 bytes.  Phase A leaves theta_s in ONE float of the slot, phase B (the lane that read it)
+  // overwrites the slot with the step's increment: 16 bytes per pair instead of 20, and the LDS footprint decides
+  // whether two 1024-lane workgroups of k_bin_count share a CU.  Trajectory j keeps its theta in word (j >> 4) & 3,
+  // so the 64 lanes of phase A (slot stride S1 * 4 words, S1 odd) write 64 different banks.
+  double2* inc = reinterpret_cast<double2*>(roll_lds);
+  __shared__ int steps_s[kRolloutMax];
+  __shared__ float vel_s[kRolloutMax][3];
+  __shared__ double dt_s[kRolloutMax];
   const int tid = threadIdx.x;
   const int l0 = block * rt;                          // first local trajectory of this workgroup
   const int nt = min(rt, k.n_local - l0);
@@ -506,24 +533,30 @@ __device__ __forceinline__ void rollout_block(const DevTick& k, const int block,
     vel_s[tid][0] = vx; vel_s[tid][1] = vy; vel_s[tid][2] = w;
     dt_s[tid] = dt;
     // theta_{k+1} = float(theta_k + w*dt)   (computeNewPositions, dd_simple...cpp:457-464)
-    float* row = th + (size_t)tid * S1;
+    float* row = reinterpret_cast<float*>(inc + (size_t)tid * S1) + ((tid >> 4) & 3);
     float a = 0.f;
     row[0] = 0.f;
     const double wdt = (double)w * dt;
     for (int s = 1; s <= ns; ++s) {
       a = (float)((double)a + wdt);
-      row[s] = a;
+      row[4 * s] = a;
     }
   }
   __syncthreads();
   DDDMR_RSTAMP(1);
 
   // ---- phase B ----
+  // (j, s) of a lane's items advance by a fixed stride: one integer division per lane, not one per item
+  const int stride_j = kThreads / S1, stride_s = kThreads - stride_j * S1;
+  int bj = tid / S1, bs = tid - bj * S1;
   for (int idx = tid; idx < nt * S1; idx += kThreads) {
-    const int j = idx / S1, s = idx - j * S1;
+    const int j = bj, s = bs;
+    bj += stride_j;
+    bs += stride_s;
+    if (bs >= S1) { bs -= S1; ++bj; }
     const int ns = steps_s[j];
     if (s <= ns) {
-      const double ang = (double)th[idx];
+      const double ang = (double)reinterpret_cast<const float*>(inc + idx)[(j >> 4) & 3];
       double sn, cs;
       sincos_heading(ang, &sn, &cs);
       // heading after step s-1 = theta_s: the pose's rotation (dd_simple...cpp:416)
@@ -546,27 +579,43 @@ __device__ __forceinline__ void rollout_block(const DevTick& k, const int block,
   DDDMR_RSTAMP(2);
 
   // ---- phase C ----  (x, y overwrite the consumed increment slots; a coalesced copy-out follows)
-  if (tid < nt) {
-    const int ns = steps_s[tid];
-    double2* ir = inc + (size_t)tid * S1;
-    float px = 0.f, py = 0.f;
-    int s = 0;
-    for (; s + 4 <= ns; s += 4) {
-      const double2 i0 = ir[s], i1 = ir[s + 1], i2 = ir[s + 2], i3 = ir[s + 3];
-      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); *reinterpret_cast<float2*>(ir + s) = make_float2(px, py);
-      px = (float)((double)px + i1.x); py = (float)((double)py + i1.y); *reinterpret_cast<float2*>(ir + s + 1) = make_float2(px, py);
-      px = (float)((double)px + i2.x); py = (float)((double)py + i2.y); *reinterpret_cast<float2*>(ir + s + 2) = make_float2(px, py);
-      px = (float)((double)px + i3.x); py = (float)((double)py + i3.y); *reinterpret_cast<float2*>(ir + s + 3) = make_float2(px, py);
-    }
-    for (; s < ns; ++s) {
-      const double2 i0 = ir[s];
-      px = (float)((double)px + i0.x); py = (float)((double)py + i0.y); *reinterpret_cast<float2*>(ir + s) = make_float2(px, py);
+  // The x and the y recurrence of a trajectory are independent chains of cvt / add / cvt: lanes [0, 128) run the x
+  // chains, lanes [128, 256) the y chains, i.e. DIFFERENT waves (on different SIMDs), which halves the dependent
+  // issue per step.  Each lane reads its double (words 0-1 or 2-3 of the slot) and writes the float position over
+  // the low word of what it read, so the two chains never touch each other's bytes.
+  static_assert(kThreads >= 2 * kRolloutMax, "phase C needs a lane per chain");
+  {
+    const int cj = tid & (kRolloutMax - 1), comp = tid >> 7;      // kRolloutMax == 128
+    if (tid < 2 * kRolloutMax && cj < nt) {
+      const int ns = steps_s[cj];
+      double* ir = reinterpret_cast<double*>(inc + (size_t)cj * S1) + comp;
+      float p = 0.f;
+      int s = 0;
+      for (; s + 4 <= ns; s += 4) {
+        const double i0 = ir[2 * s], i1 = ir[2 * s + 2], i2 = ir[2 * s + 4], i3 = ir[2 * s + 6];
+        p = (float)((double)p + i0); *reinterpret_cast<float*>(ir + 2 * s) = p;
+        p = (float)((double)p + i1); *reinterpret_cast<float*>(ir + 2 * s + 2) = p;
+        p = (float)((double)p + i2); *reinterpret_cast<float*>(ir + 2 * s + 4) = p;
+        p = (float)((double)p + i3); *reinterpret_cast<float*>(ir + 2 * s + 6) = p;
+      }
+      for (; s < ns; ++s) {
+        p = (float)((double)p + ir[2 * s]);
+        *reinterpret_cast<float*>(ir + 2 * s) = p;
+      }
     }
   }
   __syncthreads();
+  bj = tid / S1;
+  bs = tid - bj * S1;
   for (int idx = tid; idx < nt * S1; idx += kThreads) {
-    const int j = idx / S1, s = idx - j * S1;
-    if (s < steps_s[j]) st_xy[(size_t)(l0 + j) * k.max_steps + s] = *reinterpret_cast<const float2*>(inc + idx);
+    const int j = bj, s = bs;
+    bj += stride_j;
+    bs += stride_s;
+    if (bs >= S1) { bs -= S1; ++bj; }
+    if (s < steps_s[j]) {
+      const float* slot = reinterpret_cast<const float*>(inc + idx);
+      st_xy[(size_t)(l0 + j) * k.max_steps + s] = make_float2(slot[0], slot[2]);
+    }
   }
   DDDMR_RSTAMP(3);
 }
@@ -684,15 +733,18 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_count(DevTick k, const f
                                                    double2* __restrict__ st_sc, float2* __restrict__ st_xy,
                                                    const uint32_t* __restrict__ load, uint32_t* __restrict__ assign) {
   extern __shared__ __attribute__((aligned(16))) unsigned char dyn_lds[];
+  // Longest first: the assignment workgroups (only launched with use_assign), the rollout, then the binning
+  // workgroups -- when the launch does not fit the chip in one round, the short ones fill the tail.
   const int n_assign = k.use_assign ? k.assign_groups : 0;
-  if ((int)blockIdx.x >= k.bin_blocks + n_assign) {
-    rollout_block<kBinThreads>(k, (int)blockIdx.x - k.bin_blocks - n_assign, axes, samples, info, st_sc, st_xy, dyn_lds);
+  if ((int)blockIdx.x < n_assign) {
+    assign_block<kBinThreads>(k, (int)blockIdx.x, load, assign);
     return;
   }
-  if ((int)blockIdx.x >= k.bin_blocks) {   // assignment blocks (only launched with use_assign)
-    assign_block<kBinThreads>(k, (int)blockIdx.x - k.bin_blocks, load, assign);
+  if ((int)blockIdx.x < n_assign + k.roll_blocks) {
+    rollout_block<kBinThreads>(k, (int)blockIdx.x - n_assign, axes, samples, info, st_sc, st_xy, dyn_lds);
     return;
   }
+  const int bin_block = (int)blockIdx.x - n_assign - k.roll_blocks;
   __shared__ uint32_t wave_sum[16];
   __shared__ uint32_t carry_s;
   __shared__ uint32_t is_last;
@@ -701,7 +753,7 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_count(DevTick k, const f
   // Every lane bins up to kBinPer points per pass, all their loads and counting atomics in
   // flight together: a quarter of the workgroups (dispatching a 1024-lane workgroup costs
   // ~12 ns, and the launch also carries the rollout's) at the latency of one point.
-  for (int base = blockIdx.x * blockDim.x + threadIdx.x; base < k.n_points; base += stride * kBinPer) {
+  for (int base = bin_block * blockDim.x + threadIdx.x; base < k.n_points; base += stride * kBinPer) {
     float4 p[kBinPer];
     uint2 slot[kBinPer];
 #pragma unroll

@@ -238,6 +238,13 @@ class LocalPlanner:
         self._check(self._lib.dddmr_rollout_stream_ceiling(self._ctx, nbytes, reps, C.byref(cp), C.byref(rd)))
         return cp.value, rd.value
 
+    def selftest_sincos(self, angles):
+        """sin / cos of heading angles from the rollout's own double routine -> (sin[n], cos[n]) f64"""
+        a = np.ascontiguousarray(angles, dtype=np.float64)
+        sn, cs = np.empty_like(a), np.empty_like(a)
+        self._check(self._lib.dddmr_rollout_selftest_sincos(self._ctx, a.ctypes.data, a.size, sn.ctypes.data, cs.ctypes.data))
+        return sn, cs
+
     # -- per-trajectory outputs of the last tick -----------------------------
     def debug(self):
         """-> (costs[n_local] f64, steps[n_local] i32, samples[n_local,3] f32)"""

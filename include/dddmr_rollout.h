@@ -424,6 +424,13 @@ int dddmr_rollout_marking_get_lethal(dddmr_rollout_ctx* ctx, uint8_t* flags_out,
 int dddmr_rollout_stream_ceiling(dddmr_rollout_ctx* ctx, size_t bytes, int32_t reps,
                                  double* copy_gbps, double* read_gbps);
 
+/* Self-test aid: sine and cosine of n heading angles from the rollout's own double-precision routine
+   (the stand-in for the libm sin / cos the reference's theories call, dd_simple...cpp:416,457-464,
+   omni_simple...cpp:498-505), so that a test can bound its error against a higher-precision value.
+   Not part of the reference's surface and not on the tick's path. */
+int dddmr_rollout_selftest_sincos(dddmr_rollout_ctx* ctx, const double* angles, size_t n,
+                                  double* sin_out, double* cos_out);
+
 const char* dddmr_rollout_last_error(dddmr_rollout_ctx* ctx);
 const char* dddmr_rollout_version(void);
 

@@ -570,3 +570,25 @@ def test_samples_entry_point_is_the_theorys_initialise():
             lp.setPlan(sc.plan)
             lp.tick(name, tick)
             np.testing.assert_array_equal(lp.debug()[2], got)
+
+
+def test_heading_sincos_is_within_one_ulp_of_long_double():
+    """The rollout's own double sin / cos (its stand-in for the libm calls of dd_simple...cpp:416,457-464 and
+    omni_simple...cpp:498-505; glibc and ocml promise <= 1 ulp) against x87 long-double values: error < 1 ulp on
+    headings a rollout can produce, quadrant boundaries and the ocml fall-back range included."""
+    rng = np.random.default_rng(11)
+    q = np.arange(-64, 65, dtype=np.float64) * (math.pi / 2)
+    ang = np.concatenate([
+        rng.uniform(-math.pi, math.pi, 20000), rng.uniform(-40.0, 40.0, 20000), rng.uniform(-1e5, 1e5, 5000),
+        rng.uniform(-1e7, 1e7, 500),                                   # > 1e5: ocml
+        q, np.nextafter(q, np.inf), np.nextafter(q, -np.inf),          # around the multiples of pi/2
+        np.float32(rng.uniform(-7.0, 7.0, 5000)).astype(np.float64),   # float headings, as the rollout's theta_k are
+        [0.0, -0.0, 1e-300, -1e-300, 1e-9, 0.785398163397448, 0.7853981633974484],
+    ])
+    with LocalPlanner([configs.omni_simple_shipped()]) as lp:
+        sn, cs = lp.selftest_sincos(ang)
+    ld = ang.astype(np.longdouble)
+    for got, ref in ((sn, np.sin(ld)), (cs, np.cos(ld))):
+        ulp = np.spacing(np.abs(ref.astype(np.float64))).astype(np.longdouble)
+        err = np.abs(got.astype(np.longdouble) - ref) / ulp
+        assert float(err.max()) < 1.0, (float(err.max()), float(ang[int(err.argmax())]))
