@@ -537,7 +537,8 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
     HIPCHK(ctx, hipMalloc(&ctx->costs, N * sizeof(double)));
     HIPCHK(ctx, hipMalloc(&ctx->steps, N * sizeof(int32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->samples_out, N * sizeof(float4)));
-    HIPCHK(ctx, hipMalloc(&ctx->best_key, 3 * sizeof(int64_t)));
+    // words 0..2: reduced argmin words; from kSlotBase on: four words per k_score workgroup (single-round shards)
+    HIPCHK(ctx, hipMalloc(&ctx->best_key, ((size_t)kSlotBase + (size_t)kSlotWords * ctx->cfg.max_trajectories) * sizeof(int64_t)));
     HIPCHK(ctx, hipMalloc(&ctx->overflow, sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&ctx->traj_load, N * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(ctx->traj_load, 0, N * sizeof(uint32_t)));

@@ -54,6 +54,11 @@ constexpr int kMaxTile = 16;          // trajectories per workgroup (upper bound
 constexpr int kMaxPlan = 512;         // prune-plan poses kept in LDS
 constexpr int kInlineAxes = 192;      // sample-axis floats that travel inside the kernel arguments
 constexpr int64_t kKeyNone = INT64_MAX;
+// best_key[]: words 0..2 are the reduced argmin words of multi-round shards (packed key, cost bits, sampled
+// collision count); from word kSlotBase on, four words per k_score workgroup for single-round shards (see the
+// tail of k_score): cost bits | global index | vx, vy | w, generated << 40, collided << 32
+constexpr int kSlotBase = 8;
+constexpr int kSlotWords = 4;
 constexpr double kMaxAcceptedCost = 9999999.0;   // local_planner.cpp:452
 // a cell-sorted point: 12 bytes -- the collision walk is bound by the bytes the lanes
 // pull through the vector L1, and the intensity word is never read
@@ -408,11 +413,25 @@ __global__ __launch_bounds__(256) void k_bin_scatter(DevTick k, const float4* __
 // cos/sin of the heading after the step (double2, the pose's AngleAxisd rotation).
 // ---------------------------------------------------------------------------
 #ifdef DDDMR_PHASE_STAMPS
-constexpr int kStampSlots = 12;
+constexpr int kStampSlots = 20;      // 0..11 s_memtime per phase, 12 / 13 s_memrealtime (100 MHz, chip-wide) at start / end, 14 XCC | CU id, 15..18 the last workgroup's hand-off
 __device__ unsigned long long g_stamps[16384 * kStampSlots];
 #define DDDMR_STAMP(i)                                                                         \
   do {                                                                                         \
-    if (threadIdx.x == 0 && blockIdx.x < 16384) g_stamps[blockIdx.x * kStampSlots + (i)] = __builtin_amdgcn_s_memtime(); \
+    if (threadIdx.x == 0 && blockIdx.x < 16384) {                                                \
+      g_stamps[blockIdx.x * kStampSlots + (i)] = __builtin_amdgcn_s_memtime();                   \
+      if ((i) == 0) {                                                                            \
+        g_stamps[blockIdx.x * kStampSlots + 12] = __builtin_amdgcn_s_memrealtime();              \
+        g_stamps[blockIdx.x * kStampSlots + 14] =                                                \
+            ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32) | \
+            (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));     \
+      }                                                                                          \
+      if ((i) == 7) g_stamps[blockIdx.x * kStampSlots + 13] = __builtin_amdgcn_s_memrealtime();  \
+    }                                                                                            \
+  } while (0)
+#define DDDMR_STAMP_RAW(i)                                                                     \
+  do {                                                                                         \
+    if ((threadIdx.x & 63) == 0 && threadIdx.x == 0 && blockIdx.x < 16384)                       \
+      g_stamps[blockIdx.x * kStampSlots + (i)] = __builtin_amdgcn_s_memtime();                   \
   } while (0)
 // rollout / assignment / binning workgroups of the k_bin_count launch: 8 slots per block
 __device__ unsigned long long g_rstamps[4096 * 8];
@@ -426,6 +445,7 @@ __device__ unsigned long long g_rstamps[4096 * 8];
   } while (0)
 #else
 #define DDDMR_STAMP(i) do { } while (0)
+#define DDDMR_STAMP_RAW(i) do { } while (0)
 #define DDDMR_RSTAMP(i) do { } while (0)
 #endif
 
@@ -1001,6 +1021,76 @@ __device__ __forceinline__ void decode_winner(const DevTick& k, const int lane, 
   }
 }
 
+// Single-round shards: wave 0 of the last workgroup reduces the workgroups' slots (see the tail of k_score) --
+// minimum cost as full doubles, equal costs -> highest index -- and publishes the result.  The loads of up to
+// 8 slots per lane (a launch of <= 512 workgroups) are all issued before the first use, beside the two other words
+// the result needs: ONE memory round trip, then six shuffle steps.
+__device__ __forceinline__ void reduce_slots(const DevTick& k, const int lane, const int n_slots,
+                                             const unsigned long long* __restrict__ slots,
+                                             const uint32_t* __restrict__ cell_start, const uint32_t* __restrict__ overflow,
+                                             DevResult* __restrict__ result, int64_t* __restrict__ words_out) {
+  constexpr int kPer = 8;
+  const uint32_t n_binned = cell_start[k.n_cells];
+  const uint32_t over = __hip_atomic_load(overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  long long bc = (long long)kKeyNone;
+  long long bi = -1;
+  unsigned long long b2 = 0, b3 = 0;
+  uint32_t n_coll = 0;
+  for (int base = 0; base < n_slots; base += 64 * kPer) {
+    unsigned long long w[kPer][kSlotWords];
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int i = base + u * 64 + lane;
+      const unsigned long long* sl = slots + (size_t)(i < n_slots ? i : 0) * kSlotWords;
+#pragma unroll
+      for (int q = 0; q < kSlotWords; ++q) w[u][q] = __hip_atomic_load(sl + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; ++u) {
+      const int i = base + u * 64 + lane;
+      if (i < n_slots) {
+        const long long c = (long long)w[u][0], gi = (long long)w[u][1];
+        n_coll += (uint32_t)((w[u][3] >> 32) & 0xFFu);
+        if (c < bc || (c == bc && gi > bi)) { bc = c; bi = gi; b2 = w[u][2]; b3 = w[u][3]; }
+      }
+    }
+  }
+  DDDMR_STAMP_RAW(16);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long oc = __shfl_xor(bc, o, 64), oi = __shfl_xor(bi, o, 64);
+    const unsigned long long o2 = __shfl_xor(b2, o, 64), o3 = __shfl_xor(b3, o, 64);
+    n_coll += __shfl_xor(n_coll, o, 64);
+    if (oc < bc || (oc == bc && oi > bi)) { bc = oc; bi = oi; b2 = o2; b3 = o3; }
+  }
+  if (lane == 0) {
+    const bool any = bc != (long long)kKeyNone;
+    DevResult r;
+    r.index = any ? (int32_t)bi : -1;
+    r.cost = any ? __longlong_as_double(bc) : -1.0;
+    r.key = any ? pack_key(r.cost, (uint32_t)r.index) : kKeyNone;
+    r.vx = any ? __uint_as_float((uint32_t)b2) : 0.f;
+    r.vy = any ? __uint_as_float((uint32_t)(b2 >> 32)) : 0.f;
+    r.wz = any ? __uint_as_float((uint32_t)b3) : 0.f;
+    r.n_binned = n_binned;
+    r.overflow = over;
+    r.seq = 0;
+    r.n_collided = n_coll;          // exact here (every workgroup reports), sampled on multi-round shards
+    DDDMR_STAMP_RAW(17);
+    *result = r;
+    if (words_out) {
+      // multi-rank context: this shard's (cost bits, -index) slot of the all-reduce that follows on
+      // the stream; `result` then is a device-side staging record and k_resolve tells the host
+      words_out[0] = any ? (int64_t)bc : kKeyNone;
+      words_out[1] = any ? -(int64_t)r.index : kKeyNone;
+    } else {
+      __threadfence_system();
+      __hip_atomic_store(&result->seq, k.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    DDDMR_STAMP_RAW(18);
+  }
+}
+
 // kLean: the common critic stack -- no min-max critic and no pair that needs the 1 m radius test
 // (the cuboid lies inside the search ball) -- as compile-time facts: the walk loses its radius /
 // min-max code and the records their optional words.
@@ -1545,10 +1635,12 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
 
   // ---- phase E: stacked scoring (stacked_scoring_model.cpp:75-93) + argmin ----
   int64_t key = kKeyNone, cbits = kKeyNone;
+  int my_gi = -1;
   if (tid < nt) {
     const TrajHead h = head[tid];
     const int li = head[tid].li;
     const int gi = k.begin + li;
+    my_gi = gi;
     double cost = DDDMR_COST_NOT_GENERATED;
     if (h.steps > 0) {
       cost = 0.0;
@@ -1605,23 +1697,13 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
         if (r < 0) { cost = r; done = true; }
         else cost += r;
       }
-      key = pack_key(cost, (uint32_t)gi);
+      if (k.final_kernel) key = pack_key(cost, (uint32_t)gi);
       cbits = cost_bits(cost);
     }
-    // cost + sample are read back by the last workgroup: device-scope (write-through)
-    // stores, matched by device-scope loads there -- no cache flush needed
-    if (k.final_kernel) {                      // the launch boundary before k_finalize publishes plain stores
-      costs[li] = cost;
-      samples_out[li] = make_float4(h.vx, h.vy, h.w, 0.f);
-    } else {
-      __hip_atomic_store(reinterpret_cast<unsigned long long*>(costs) + li,
-                         (unsigned long long)__double_as_longlong(cost), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      float* so = reinterpret_cast<float*>(samples_out + li);
-      __hip_atomic_store(so + 0, h.vx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(so + 1, h.vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(so + 2, h.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      so[3] = 0.f;
-    }
+    // per-trajectory outputs: plain stores (nothing on the device reads them before the launch ends: k_finalize
+    // comes after the launch boundary, and a single-round shard's last workgroup works from the workgroup slots)
+    costs[li] = cost;
+    samples_out[li] = make_float4(h.vx, h.vy, h.w, 0.f);
     steps_out[li] = h.steps;
     // what this trajectory cost (in collision work items): the walk, the path critics'
     // 1-NN searches when it got that far, and the per-pair phases
@@ -1629,71 +1711,102 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
     traj_load[li] = (uint32_t)h.walked + (uint32_t)h.steps * (2u + (collided ? 0u : (uint32_t)((k.m + 15) >> 4)));
   }
   DDDMR_STAMP(11);  // end of the stacked scoring + per-trajectory stores
-  // Wave-0 min-reduction, one pair of atomics per workgroup.  Two words are reduced: the packed
-  // key (top 40 bits of the cost | inverted index: one atomicMin yields minimum cost AND, among
-  // costs equal in those bits, the highest index) and the cost's full bit pattern.  The decode
-  // below uses the second to make the winner exact.
-  if (tid < 64) {
-    static_assert(kMaxTile <= 16, "only lanes 0..kMaxTile-1 hold keys");
-    {
-      long long kk = (long long)key, cc = (long long)cbits, o;
-      o = dpp_row_shl<8>(kk); kk = o < kk ? o : kk;
-      o = dpp_row_shl<4>(kk); kk = o < kk ? o : kk;
-      o = dpp_row_shl<2>(kk); kk = o < kk ? o : kk;
-      o = dpp_row_shl<1>(kk); kk = o < kk ? o : kk;
-      o = dpp_row_shl<8>(cc); cc = o < cc ? o : cc;
-      o = dpp_row_shl<4>(cc); cc = o < cc ? o : cc;
-      o = dpp_row_shl<2>(cc); cc = o < cc ? o : cc;
-      o = dpp_row_shl<1>(cc); cc = o < cc ? o : cc;
-      key = (int64_t)kk;                                   // lane 0: minimum of lanes 0..15
-      cbits = (int64_t)cc;
-    }
-    // Same-address device-scope atomics serialise (~4 ns each) and the workgroups of a balanced launch all arrive
-    // here together: a workgroup first LOOKS at the running minima (plain device-scope loads, served in parallel)
-    // and only issues an atomicMin for a word it can still lower.  The minima only ever decrease, so a stale
-    // (larger) value can cause a superfluous atomic, never a missing one.
-    // (Shards that run as ONE round keep the unconditional pair: there the look is a ~1.5 us round trip on the
-    // launch's critical tail -- C2 k_score 33.6 vs 35.1 us -- while multi-round shards gain: C3 126.5 -> 122 us.)
-    if (tid == 0 && key != kKeyNone) {
-      if (k.final_kernel) {
+  // ---- argmin hand-off ----
+  // Multi-round shards (k.final_kernel): wave-0 min-reduction of two words -- the packed key (top 40 bits of the
+  // cost | inverted index: one atomicMin yields minimum cost AND, among costs equal in those bits, the highest
+  // index) and the cost's full bit pattern, which makes k_finalize's decode exact -- and one pair of atomicMins.
+  if (k.final_kernel) {
+    if (tid < 64) {
+      static_assert(kMaxTile <= 16, "only lanes 0..kMaxTile-1 hold keys");
+      {
+        long long kk = (long long)key, cc = (long long)cbits, o;
+        o = dpp_row_shl<8>(kk); kk = o < kk ? o : kk;
+        o = dpp_row_shl<4>(kk); kk = o < kk ? o : kk;
+        o = dpp_row_shl<2>(kk); kk = o < kk ? o : kk;
+        o = dpp_row_shl<1>(kk); kk = o < kk ? o : kk;
+        o = dpp_row_shl<8>(cc); cc = o < cc ? o : cc;
+        o = dpp_row_shl<4>(cc); cc = o < cc ? o : cc;
+        o = dpp_row_shl<2>(cc); cc = o < cc ? o : cc;
+        o = dpp_row_shl<1>(cc); cc = o < cc ? o : cc;
+        key = (int64_t)kk;                                   // lane 0: minimum of lanes 0..15
+        cbits = (int64_t)cc;
+      }
+      // Same-address device-scope atomics serialise (~4 ns each): a workgroup first LOOKS at the running minima
+      // (plain device-scope loads, served in parallel) and only issues an atomicMin for a word it can still lower.
+      // The minima only ever decrease, so a stale (larger) value can cause a superfluous atomic, never a missing
+      // one (C3 k_score 126.5 -> 122 us).
+      if (tid == 0 && key != kKeyNone) {
         const long long cur_k = (long long)__hip_atomic_load(best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long cur_c = (long long)__hip_atomic_load(best_key + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((long long)key < cur_k) atomicMin((long long*)best_key, (long long)key);
         if ((long long)cbits < cur_c) atomicMin((long long*)best_key + 1, (long long)cbits);
-      } else {
-        atomicMin((long long*)best_key, (long long)key);
-        atomicMin((long long*)best_key + 1, (long long)cbits);
+      }
+      // How many trajectories the collision critics rejected -- a SAMPLE (every 16th workgroup; tiles are dealt as
+      // representative mixes): the next tick's walk starts with a probe round only when most do (the probe settles
+      // colliding trajectories early and is pure overhead otherwise).  Word 2 counts the sampled collided
+      // trajectories in its low half and the sampled trajectories in its high half.
+      if ((blockIdx.x & 15u) == 0u) {
+        const bool gen = tid < nt && head[tid].steps > 0;
+        const bool coll = gen && cloud_ok && ((need_box && head[tid].hit_box) || (need_mm && head[tid].hit_mm));
+        const unsigned long long cm = __ballot(coll), gm = __ballot(gen);
+        if (tid == 0 && gm)
+          atomicAdd((unsigned long long*)best_key + 2, ((unsigned long long)__popcll(gm) << 32) | (unsigned long long)__popcll(cm));
       }
     }
-    // How many trajectories the collision critics rejected -- a SAMPLE (every 16th workgroup; tiles are dealt as
-    // representative mixes): the next tick's walk starts with a probe round only when most do (the probe settles
-    // colliding trajectories early and is pure overhead otherwise).  Word 2 counts the sampled collided
-    // trajectories in its low half and the sampled trajectories in its high half.
-    if ((blockIdx.x & 15u) == 0u) {
-      const bool gen = tid < nt && head[tid].steps > 0;
-      const bool coll = gen && cloud_ok && ((need_box && head[tid].hit_box) || (need_mm && head[tid].hit_mm));
-      const unsigned long long cm = __ballot(coll), gm = __ballot(gen);
-      if (tid == 0 && gm)
-        atomicAdd((unsigned long long*)best_key + 2, ((unsigned long long)__popcll(gm) << 32) | (unsigned long long)__popcll(cm));
-    }
+    // nothing more to do here -- k_finalize decodes after the launch, so a workgroup neither waits for its stores
+    // nor pays a device-scope ticket round trip while it holds a slot that the next workgroup is waiting for.
+    DDDMR_STAMP(7);
+    return;
   }
-  // ---- winner decode ----
-  // Big shards (several rounds of workgroups): nothing more to do here -- k_finalize decodes after the launch, so
-  // a workgroup neither waits for its stores nor pays a device-scope ticket round trip while it holds a slot.
-  if (k.final_kernel) { DDDMR_STAMP(7); return; }
-  // Small shards: the workgroup that draws the last ticket decodes (no finalize launch, no D2H copy).
-  // Placement-independent hand-off: every byte handed over (key, cost, sample, capacity flag) is written with
-  // device-scope atomics / write-through stores and read with device-scope loads; waves drain their stores,
-  // barrier, one relaxed device-scope ticket.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // Single-round shards: all workgroups of the launch finish within a few microseconds of each other, and what they
+  // used to do then -- two atomicMins and a ticket on the SAME addresses -- queued up behind one another (C2: 3.6 us
+  // of a workgroup's 23 us on average, 8.6 us for the unluckiest, which is what the launch waits for).  Now every
+  // workgroup leaves its exact local winner in its OWN slot (four 8-byte write-through stores: cost bits, global
+  // index, the sample, its collision counts) and draws a ticket; the workgroup that draws the last one reduces the
+  // slots (minimum cost as full doubles, equal costs -> highest index: local_planner.cpp:456-463) and publishes the
+  // result.  Placement-independent hand-off: slots are written with device-scope stores and read with device-scope
+  // loads.
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(best_key) + kSlotBase;
   if (tid < 64) {
+    long long cc = (long long)cbits;
+    int gi_w = my_gi;
+    {
+      long long oc; int oi; bool take;
+      oc = dpp_row_shl<8>(cc); oi = dpp_row_shl<8>(gi_w); take = oc < cc || (oc == cc && oi > gi_w); cc = take ? oc : cc; gi_w = take ? oi : gi_w;
+      oc = dpp_row_shl<4>(cc); oi = dpp_row_shl<4>(gi_w); take = oc < cc || (oc == cc && oi > gi_w); cc = take ? oc : cc; gi_w = take ? oi : gi_w;
+      oc = dpp_row_shl<2>(cc); oi = dpp_row_shl<2>(gi_w); take = oc < cc || (oc == cc && oi > gi_w); cc = take ? oc : cc; gi_w = take ? oi : gi_w;
+      oc = dpp_row_shl<1>(cc); oi = dpp_row_shl<1>(gi_w); take = oc < cc || (oc == cc && oi > gi_w); cc = take ? oc : cc; gi_w = take ? oi : gi_w;
+    }
+    const int win_gi = __builtin_amdgcn_readfirstlane(gi_w);         // lane 0: the tile's winner (cost bits in its cc)
+    const bool gen = tid < nt && head[tid].steps > 0;
+    const bool coll = gen && cloud_ok && ((need_box && head[tid].hit_box) || (need_mm && head[tid].hit_mm));
+    const unsigned long long cm = __ballot(coll), gm = __ballot(gen);
+    const unsigned long long wm = __ballot(tid < nt && my_gi == win_gi);
+    if (tid == 0) {
+      float vx = 0.f, vy = 0.f, w = 0.f;
+      if (cc != (long long)kKeyNone && wm) {
+        const int wl = __ffsll((long long)wm) - 1;
+        vx = head[wl].vx; vy = head[wl].vy; w = head[wl].w;
+      }
+      unsigned long long* sl = slots + (size_t)blockIdx.x * kSlotWords;
+      __hip_atomic_store(sl + 0, (unsigned long long)cc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sl + 1, (unsigned long long)(long long)win_gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sl + 2, (unsigned long long)__float_as_uint(vx) | ((unsigned long long)__float_as_uint(vy) << 32),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(sl + 3, (unsigned long long)__float_as_uint(w) | ((unsigned long long)__popcll(cm) << 32) |
+                                     ((unsigned long long)__popcll(gm) << 40),
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // wave 0 alone goes on (the other waves are done: nothing they wrote is read on the device again): its slot
+    // stores drained, one relaxed device-scope ticket, and the wave that draws the last one reduces
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t t = 0;
     if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+    DDDMR_STAMP_RAW(15);
     if (t == gridDim.x - 1) {
       if (lane == 0) *ticket = 0;
-      decode_winner(k, lane, best_key, costs, samples_out, cell_start, overflow, result, words_out);
+      reduce_slots(k, lane, (int)gridDim.x, slots, cell_start, overflow, result, words_out);
     }
   }
   DDDMR_STAMP(7);

@@ -17,14 +17,14 @@ with LocalPlanner([sc.theory], max_points=max(len(sc.cloud), 16)) as lp:
     name = sc.theory.name.decode()
     for _ in range(5):
         r = lp.tick(name, sc.tick)
-    SL = 12
+    SL = 20
     n_wg = 16384
     buf = np.zeros(n_wg * SL, dtype=np.uint64)
     lib.dddmr_rollout_diag_stamps.argtypes = [C.c_void_p, C.c_size_t]
     assert lib.dddmr_rollout_diag_stamps(buf.ctypes.data_as(C.c_void_p), buf.size) == 0
     st = buf.reshape(n_wg, SL)
     st = st.astype(np.int64)
-    nwg = int(os.environ.get('EXP_NWG', '1366'))
+    nwg = int(os.environ.get('EXP_NWG', '16384'))
     used = np.zeros(len(st), bool); used[:nwg] = True
     used &= st[:, 7] > 0
     st = st[used]
@@ -48,3 +48,26 @@ with LocalPlanner([sc.theory], max_points=max(len(sc.cloud), 16)) as lp:
     print(f"  start times: p50 {np.percentile(start,50):.2f} p90 {np.percentile(start,90):.2f} max {start.max():.2f} us")
     tot = st[:, 9]
     print(f"  items per wg: mean {tot.mean():.0f} max {tot.max()}  corr(items, D3 time) {np.corrcoef(tot, st[:,6]-st[:,5])[0,1]:.3f}")
+
+    # chip-wide timeline from s_memrealtime (100 MHz): when workgroups start / end, how many are resident, per-CU share
+    w0 = st[:, 12].min()
+    ws = (st[:, 12] - w0) / 100.0; we = (st[:, 13] - w0) / 100.0
+    span = we.max()
+    print(f"  wall: first start 0, last start {ws.max():.2f} us, last end {span:.2f} us; workgroup life p50 {np.percentile(we-ws,50):.2f} p90 {np.percentile(we-ws,90):.2f} max {(we-ws).max():.2f} us")
+    grid = np.linspace(0.0, span, 13)[:-1]
+    res = [(int(((ws <= t) & (we > t)).sum())) for t in grid]
+    print("  resident workgroups at", " ".join(f"{t:.0f}us:{n}" for t, n in zip(grid, res)))
+    hw = st[:, 14]
+    xcc = (hw >> 32) & 0xF; hid = hw & 0xFFFFFFFF
+    cu = (xcc << 8) | (((hid >> 13) & 7) << 5) | (((hid >> 12) & 1) << 4) | ((hid >> 8) & 0xF)
+    ucu, cnt = np.unique(cu, return_counts=True)
+    busy = np.array([(we[cu == c] - ws[cu == c]).sum() for c in ucu])
+    print(f"  CUs used {len(ucu)}; workgroups per CU min {cnt.min()} p50 {int(np.median(cnt))} max {cnt.max()}; per-CU busy (sum of lives / 2 slots) p10 {np.percentile(busy,10)/2:.1f} p50 {np.percentile(busy,50)/2:.1f} p90 {np.percentile(busy,90)/2:.1f} max {busy.max()/2:.1f} us of {span:.1f}")
+    x, xc = np.unique(xcc, return_counts=True)
+    print("  workgroups per XCC:", dict(zip(x.tolist(), xc.tolist())))
+
+    # the last workgroup's hand-off (single-round shards): ticket drawn -> slots loaded -> reduced -> published
+    last = int(np.argmax(st[:, 18])) if st[:, 18].max() > 0 else -1
+    if last >= 0:
+        t = st[last]
+        print(f"  last workgroup: stores+ticket {(t[15]-t[11])/1000.0:.2f} kc | slot loads + wave reduce {(t[16]-t[15])/1000.0:.2f} | cross-wave reduce {(t[17]-t[16])/1000.0:.2f} | result + system fence + seq {(t[18]-t[17])/1000.0:.2f}")
