@@ -39,13 +39,7 @@ with LocalPlanner([sc.theory], max_points=max(len(sc.cloud), 16)) as lp:
     e1 = (st[:, 10] - st[:, 8]) / 1000.0; e2 = (st[:, 11] - st[:, 10]) / 1000.0; e3 = (st[:, 7] - st[:, 11]) / 1000.0
     print(f"    E split: StickPath sums mean {e1.mean():6.2f} kc | stacked scoring + stores mean {e2.mean():6.2f} | reduce + atomics (+ ticket) mean {e3.mean():6.2f} max {e3.max():6.2f}")
     life = (st[:, 7] - st[:, 0]) / 1000.0
-    print(f"  workgroup lifetime mean {life.mean():.2f} us max {life.max():.2f} us; first start -> last end {(st[:,7].max()-t0)/1000.0:.2f} us")
-    start = (st[:, 0] - t0) / 1000.0
-    end = (st[:, 7] - t0) / 1000.0
-    order = np.argsort(start)
-    print("  start-time deciles (kc):", np.round(np.percentile(start, [0,10,20,30,40,50,60,70,80,90,100]),1))
-    print("  end-time deciles (kc):  ", np.round(np.percentile(end, [0,10,20,30,40,50,60,70,80,90,100]),1))
-    print(f"  start times: p50 {np.percentile(start,50):.2f} p90 {np.percentile(start,90):.2f} max {start.max():.2f} us")
+    print(f"  workgroup lifetime mean {life.mean():.2f} kc max {life.max():.2f} kc (s_memtime runs per XCC: only differences inside a workgroup mean anything; ~2.2 kc per us)")
     tot = st[:, 9]
     print(f"  items per wg: mean {tot.mean():.0f} max {tot.max()}  corr(items, D3 time) {np.corrcoef(tot, st[:,6]-st[:,5])[0,1]:.3f}")
 
