@@ -219,3 +219,51 @@ def test_winner_is_the_last_exact_minimum_of_the_engines_own_costs(cfg):
     la = last_argmin(costs)
     assert res.best_index == la and res.best_cost == costs[la]
     assert res.key == sharding.pack_key(costs[la], la)
+
+
+# The engine picks its launch shapes and hand-off paths by shard size and by feedback from the previous tick; every
+# one of them can also be forced through the environment (read when the context is created).  Whatever is forced, the
+# per-trajectory outputs and the winner must be the ones of the default path, bit for bit.
+FORCED = [
+    {"DDDMR_FINAL": "0"},          # last-workgroup slot reduce, also on a multi-round shard (> 512 slots)
+    {"DDDMR_FINAL": "1"},          # k_finalize decode, also on a single-round shard
+    {"DDDMR_PROBE": "0"}, {"DDDMR_PROBE": "1"},
+    {"DDDMR_RT": "16"}, {"DDDMR_RT": "128"},
+    {"DDDMR_THREADS": "256"},
+    {"DDDMR_NO_ASSIGN": "1"}, {"DDDMR_NO_TAB": "1"},
+]
+
+
+@pytest.mark.parametrize("cfg", ["C2", "C3"])
+def test_forced_launch_shapes_and_hand_off_paths_change_nothing(cfg):
+    sc = scenes.bench_scene(cfg)
+
+    def run():
+        with LocalPlanner([sc.theory], max_points=len(sc.cloud), max_trajectories=1 << 15) as lp:
+            lp.set_cloud(sc.cloud)
+            lp.setPlan(sc.plan)
+            out = []
+            for _ in range(3):           # tick 1: no load feedback, probe on; ticks 2, 3: steady state
+                res = lp.tick(sc.theory.name.decode(), sc.tick)
+                costs, steps, smp = lp.debug()
+                out.append((res.best_index, res.best_cost, (res.vx, res.vy, res.wz), res.key, costs.copy(), steps.copy(), smp.copy()))
+            return out
+
+    base = run()
+    for env in FORCED:
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            got = run()
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        for (bi, bc, bv, bk, c0, s0, m0), (gi, gc, gv, gk, c1, s1, m1) in zip(base, got):
+            assert (gi, gc, gk) == (bi, bc, bk), env
+            assert tuple(gv) == tuple(bv), env
+            np.testing.assert_array_equal(c1, c0, err_msg=str(env))
+            np.testing.assert_array_equal(s1, s0, err_msg=str(env))
+            np.testing.assert_array_equal(m1, m0, err_msg=str(env))
