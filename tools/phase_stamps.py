@@ -65,3 +65,12 @@ with LocalPlanner([sc.theory], max_points=max(len(sc.cloud), 16)) as lp:
     if last >= 0:
         t = st[last]
         print(f"  last workgroup: stores+ticket {(t[15]-t[11])/1000.0:.2f} kc | slot loads + wave reduce {(t[16]-t[15])/1000.0:.2f} | cross-wave reduce {(t[17]-t[16])/1000.0:.2f} | result + system fence + seq {(t[18]-t[17])/1000.0:.2f}")
+
+    # the slowest workgroups against the median: which phase makes the launch wait
+    lifew = we - ws
+    order = np.argsort(-lifew)[:6]
+    cols = [("A", 0, 1), ("D1", 3, 4), ("D2", 4, 5), ("D3", 5, 6), ("P", 6, 8), ("E", 8, 7)]
+    med = {nm: np.median((st[:, b] - st[:, a]) / 1000.0) for nm, a, b in cols}
+    print("  median phases (kc):", " ".join(f"{nm} {med[nm]:.1f}" for nm, _, _ in cols), f"| life {np.median(lifew):.1f} us, items {np.median(tot):.0f}")
+    for i in order:
+        print(f"  slow wg: life {lifew[i]:.1f} us start {ws[i]:.2f} items {tot[i]:5d} |", " ".join(f"{nm} {(st[i, b] - st[i, a]) / 1000.0:.1f}" for nm, a, b in cols))
