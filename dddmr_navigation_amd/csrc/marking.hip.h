@@ -128,7 +128,8 @@ struct MarkParams {
 
 struct MarkCounters {         // device counters of one update (copied back for dddmr_marking_stats)
   uint32_t n_clusters, n_marked, n_in_window, n_cleared, n_alive, pool_used, overflow, n_groups2, n_groups3, n_clusters_kept;
-  uint32_t n_removed, pad;
+  uint32_t n_removed;
+  uint32_t n_dup;   // clusters of this update that found their voxel already claimed by another one (marking_fix_ties)
 };
 
 // isinLidarObservation (:682-746).  The reference builds a rotation that turns the x axis onto the viewing
@@ -495,7 +496,10 @@ __global__ __launch_bounds__(256) void k_mk_proj_keys(MarkParams k, const uint32
 }
 
 // Marking::addPCPtr, slot part: marking_[x][y][z] is created or found; when several clusters of one scan land on the
-// same voxel the last one in PCL's order (clusters sorted by size, descending) keeps the slot.
+// same voxel the last one in PCL's order (clusters sorted by size, descending) keeps the slot.  Among clusters of
+// EQUAL size that order is whatever libstdc++'s introsort leaves (std::sort over reverse iterators,
+// pcl/segmentation/impl/extract_clusters.hpp): the priority below breaks such ties by cluster index, and the host
+// replays the very sort for the updates that have a contested voxel at all (n_dup > 0, marking_fix_ties).
 __global__ __launch_bounds__(64) void k_mk_slots(MarkParams k, const MarkCounters* __restrict__ cnt_in, ClusterArrays c, MarkStore s,
                                                  MarkCounters* __restrict__ cnt) {
   const uint32_t ci = blockIdx.x * 64 + threadIdx.x;
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(64) void k_mk_slots(MarkParams k, const MarkCounter
   if (!found) { atomicOr(&cnt->overflow, 1u); c.state[ci] = 3u; return; }   // store full: the cluster still updates the dGraph
   c.slot[ci] = slot;
   const unsigned long long pr = ((unsigned long long)((1u << 20) - min(c.size[ci], (1u << 20) - 1u)) << 20) | (unsigned long long)(ci + 1u);
-  atomicMax(&s.owner[slot], pr);
+  if (atomicMax(&s.owner[slot], pr) != 0ull) atomicAdd(&cnt->n_dup, 1u);
   atomicAdd(&cnt->n_marked, 1u);
 }
 // ... storage part: the winning cluster's generator points go to the pool
@@ -555,6 +559,29 @@ __global__ __launch_bounds__(256) void k_mk_dgraph(MarkParams k, const uint32_t*
       if (d <= k.inscribed) s.lethal[node] = 1;
     }
   });
+}
+// marking_fix_ties: the generator points of the cluster that keeps a contested voxel in the reference's order replace
+// the ones k_mk_commit stored (those become pool garbage).  One wave per (slot, cluster) pair.
+__global__ __launch_bounds__(256) void k_mk_fix_owner(MarkParams k, uint32_t n_fix, const uint2* __restrict__ fix,
+                                                      const float4* __restrict__ gen, ClusterArrays c, MarkStore s,
+                                                      MarkCounters* __restrict__ cnt) {
+  const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (f >= n_fix) return;
+  const uint32_t slot = fix[f].x, ci = fix[f].y;
+  const uint32_t n = c.gen_count[ci], first = c.gen_first[ci];
+  uint32_t ofs = 0;
+  if (lane == 0) ofs = atomicAdd(&cnt->pool_used, n);
+  ofs = (uint32_t)__builtin_amdgcn_readfirstlane((int)ofs);
+  if (ofs + n > k.pool_cap) {
+    if (lane == 0) { atomicOr(&cnt->overflow, 2u); s.alive[slot] = 0; s.pts_n[slot] = 0; }
+    return;
+  }
+  for (uint32_t i = lane; i < n; i += 64) {
+    const float4 p = gen[first + i];
+    s.pool[ofs + i] = make_float4(p.x, p.y, p.z, 0.f);
+  }
+  if (lane == 0) { s.pts_ofs[slot] = ofs; s.pts_n[slot] = n; s.alive[slot] = 1; }
 }
 __global__ __launch_bounds__(256) void k_mk_finish(MarkParams k, MarkStore s, MarkCounters* __restrict__ cnt) {
   const uint32_t slot = blockIdx.x * 256 + threadIdx.x;

@@ -3,6 +3,8 @@
 // launch sequence and the dddmr_rollout_marking_* entry points of include/dddmr_rollout.h.
 #pragma once
 
+#include <unordered_map>
+
 #include "marking.hip.h"
 
 namespace {
@@ -46,6 +48,17 @@ void free_grid(GridBuf& b) {
   if (b.g.sorted) (void)hipFree(b.g.sorted);
   b = GridBuf();
 }
+
+// Contested voxels.  When several accepted clusters of one scan have their centroid in the same voxel, the reference
+// keeps the generator points of the one processed LAST, and it processes the clusters in the order
+// std::sort(clusters.rbegin(), clusters.rend(), comparePointClusters) leaves them in (EuclideanClusterExtraction::
+// extract): descending size, equal sizes in the order libstdc++'s introsort happens to produce.  k_mk_slots breaks
+// equal sizes by cluster index; for the (rare) updates that have a contested voxel this replays the reference's sort on
+// the host -- the same std::sort, on the same sizes in the same creation order (ascending first point index =
+// ascending cluster index), with a comparator that compares sizes only -- and re-commits the voxels whose keeper
+// differs.  The dGraph and the lethal set do not depend on the keeper (every cluster contributes its minimum); what does
+// is which node set a later selfClear of the voxel resets.
+int marking_fix_ties(dddmr_rollout_ctx* ctx, MarkingState* m, const MarkParams& k, const MarkStore& s, MarkCounters& out);
 
 void marking_free(MarkingState* m) {
   if (!m) return;
@@ -172,6 +185,51 @@ int upload_static(dddmr_rollout_ctx* ctx, MarkingState* m, GridBuf& b, float4** 
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   (void)hipFree(slot);
   return rb;
+}
+
+int marking_fix_ties(dddmr_rollout_ctx* ctx, MarkingState* m, const MarkParams& k, const MarkStore& s, MarkCounters& out) {
+  const uint32_t nc = out.n_clusters;
+  if (nc == 0) return DDDMR_OK;
+  hipStream_t st = ctx->stream;
+  std::vector<uint32_t> size(nc), state(nc), slot(nc);
+  HIPCHK(ctx, hipMemcpyAsync(size.data(), m->cl.size, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipMemcpyAsync(state.data(), m->cl.state, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipMemcpyAsync(slot.data(), m->cl.slot, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  // what extractEuclideanClusters hands to the sort: the clusters of at least min_cluster_size points, in creation order
+  struct Item { uint32_t size, ci; };
+  std::vector<Item> order;
+  order.reserve(nc);
+  for (uint32_t ci = 0; ci < nc; ++ci)
+    if ((int)size[ci] >= m->cfg.euclidean_cluster_extraction_min_cluster_size) order.push_back(Item{size[ci], ci});
+  std::sort(order.rbegin(), order.rend(), [](const Item& a, const Item& b) { return a.size < b.size; });
+  // per contested voxel: the accepted cluster the reference processes last, against the one the device kept
+  struct Keep { uint32_t ref_ci, dev_ci, dev_size, claims; };
+  std::unordered_map<uint32_t, Keep> keep;
+  for (const Item& it : order) {                      // (processing order)
+    if (state[it.ci] != 2u) continue;
+    auto ins = keep.insert(std::make_pair(slot[it.ci], Keep{it.ci, it.ci, it.size, 1u}));
+    if (ins.second) continue;
+    Keep& kp = ins.first->second;
+    kp.ref_ci = it.ci;
+    ++kp.claims;
+    if (it.size < kp.dev_size || (it.size == kp.dev_size && it.ci > kp.dev_ci)) { kp.dev_ci = it.ci; kp.dev_size = it.size; }   // k_mk_slots' priority
+  }
+  std::vector<uint2> fix;
+  for (const auto& kv : keep)
+    if (kv.second.claims > 1 && kv.second.ref_ci != kv.second.dev_ci) fix.push_back(make_uint2(kv.first, kv.second.ref_ci));
+  if (fix.empty()) return DDDMR_OK;
+  // (vals_a is scratch of the update that just finished: >= max_obs words)
+  uint2* fix_dev = reinterpret_cast<uint2*>(m->vals_b);
+  if (fix.size() * 2 > (size_t)m->max_obs) return fail(ctx, DDDMR_ERR_CAPACITY, "marking_update: %zu contested voxels", fix.size());
+  HIPCHK(ctx, hipMemcpyAsync(fix_dev, fix.data(), fix.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(k_mk_fix_owner, dim3((unsigned)((fix.size() + 3) / 4)), dim3(256), 0, st, k, (uint32_t)fix.size(), fix_dev,
+                     m->gen, m->cl, s, m->counters);
+  HIPCHK(ctx, hipMemcpyAsync(&out, m->counters, sizeof(out), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));               // (also keeps `fix` alive until the copy has run)
+  HIPCHK(ctx, hipGetLastError());
+  m->pool_used_host = out.pool_used;
+  return DDDMR_OK;
 }
 
 int marking_reset_locked(dddmr_rollout_ctx* ctx);
@@ -480,6 +538,10 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
   HIPCHK(ctx, hipGetLastError());
   m->pool_used_host = out.pool_used;
   m->n_alive_host = out.n_alive;
+  if (out.n_dup > 0 && !out.overflow) {
+    const int rc = marking_fix_ties(ctx, m, k, s, out);
+    if (rc != DDDMR_OK) return rc;
+  }
   if (stats) {
     stats->n_observation = n_obs > 5 ? n_obs : 0;
     stats->n_clusters = out.n_clusters_kept;
