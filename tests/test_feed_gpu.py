@@ -2,6 +2,8 @@
 oracle's restatement of MultiLayerSpinningLidar::cbSensor.  PCL accumulates
 voxel centroids in float in an unspecified order, so agreement is to 1e-5 m,
 compared voxel by voxel."""
+import math
+
 import numpy as np
 import pytest
 
@@ -113,3 +115,33 @@ def test_stitcher_feeds_the_last_n_raw_scans_through_the_current_transforms():
         lp.set_stitcher(0)                                   # off again: only the newest scan
         n = lp.set_scan(scans[0], tbs, (0, 0, 0, 0, 0, 0, 1), 8.0, 1.8)
         assert n == len(oracle.feed(scans[0], tbs, (0, 0, 0, 0, 0, 0, 1), 8.0, 1.8))
+
+
+import os
+
+
+# DDDMR_FEED_SEEDS=N widens the sweep for a soak run (default 3 keeps the suite short)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DDDMR_FEED_SEEDS", "3"))))
+def test_random_scans_and_transforms(seed):
+    """Random sensor mounts, robot poses (any yaw, ramps up to ~15 deg), crop windows and scan sizes: the same voxel
+    set as the oracle's cbSensor restatement, centroids within 1e-5 m."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(500 + seed)
+    cloud = scenes.cloud_c2()
+    tbs = (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2)), float(rng.uniform(0.2, 0.9))) + \
+        tuple(scenes.quat_from_rpy(float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-0.1, 0.1)), float(rng.uniform(-0.2, 0.2))))
+    tgb = (float(rng.uniform(-4, 4)), float(rng.uniform(-2, 2)), float(rng.uniform(-0.1, 0.1))) + \
+        tuple(scenes.quat_from_rpy(float(rng.uniform(-0.25, 0.25)), float(rng.uniform(-0.25, 0.25)), float(rng.uniform(-math.pi, math.pi))))
+    window, height = float(rng.uniform(2.0, 12.0)), float(rng.uniform(0.5, 2.5))
+    scan = scenes.lidar_scan(cloud, sensor_xyz=(tgb[0], tgb[1], tgb[2] + tbs[2]), seed=int(rng.integers(1 << 20)))
+    keep = int(rng.choice([len(scan), len(scan) // 3, 50, 7]))
+    scan = scan[rng.permutation(len(scan))[:keep]]
+    ref = oracle.feed(scan, tbs, tgb, window, height)
+    with LocalPlanner([configs.bench_theory("C2")], max_points=40_000) as lp:
+        n = lp.set_scan(scan, tbs, tgb, window, height)
+        got = lp.get_cloud()
+    assert n == len(ref) == len(got)
+    if n:
+        d, idx = cKDTree(ref[:, :3]).query(got[:, :3])
+        assert d.max() <= 1e-5
+        assert len(np.unique(idx)) == len(ref)
