@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from dddmr_navigation_amd import _capi as K, configs, scenes
+from dddmr_navigation_amd import _capi as K, configs, scenes, sharding
 from dddmr_navigation_amd.local_planner import LocalPlanner
 import oracle
 
@@ -167,3 +167,48 @@ def test_random_scenario(seed, permuted):
     else:
         STATS["runs_with_fragile_flip"] += 1
         STATS["runs_winner_unchecked_after_flip"] += 1
+
+
+# DDDMR_RANDOM_SHARD_SEEDS=N widens the sweep (default 12)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DDDMR_RANDOM_SHARD_SEEDS", "12"))))
+def test_random_scenario_sharded_over_contexts(seed):
+    """The random scenarios again, cut into 2..7 contiguous shards (one context each, all on this GPU): the shards'
+    per-trajectory outputs tile the unsharded ones bit for bit, and the exact slot-vector resolve
+    (dddmr_rollout_winner_words / _resolve_words: minimum cost as full doubles, equal costs -> highest index) yields
+    the unsharded winner and command on every rank."""
+    rng = np.random.default_rng(1000 + seed)
+    th, cloud, plan, tick = random_case(rng, permute_stack=bool(seed & 1))
+    world = int(np.random.default_rng(7000 + seed).integers(2, 8))
+    with LocalPlanner([th], max_points=max(len(cloud), 16), max_steps=512) as lp:
+        lp.set_cloud(cloud)
+        lp.setPlan(plan)
+        res0 = lp.tick("t", tick)
+        costs0, steps0, smp0 = (a.copy() for a in lp.debug())
+    ctxs, words, parts = [], [], []
+    try:
+        for r in range(world):
+            lp = LocalPlanner([th], max_points=max(len(cloud), 16), max_steps=512, rank=r, world_size=world)
+            ctxs.append(lp)
+            lp.set_cloud(cloud)
+            lp.setPlan(plan)
+            res = lp.tick("t", tick)
+            b, e = sharding.shard_range(r, world, res.n_samples)
+            assert (res.local_begin, res.n_local) == (b, e - b)
+            c, s, m = lp.debug()
+            parts.append((c[:e - b].copy(), s[:e - b].copy(), m[:e - b].copy()))
+            words.append(lp.winner_words(res))
+        np.testing.assert_array_equal(np.concatenate([p[0] for p in parts]), costs0[:res0.n_samples])
+        np.testing.assert_array_equal(np.concatenate([p[1] for p in parts]), steps0[:res0.n_samples])
+        np.testing.assert_array_equal(np.concatenate([p[2] for p in parts]), smp0[:res0.n_samples])
+        slots = [2 ** 63 - 1] * (2 * world)
+        for r, (w0, w1) in enumerate(words):
+            slots[2 * r], slots[2 * r + 1] = w0, w1
+        for lp in ctxs:
+            out = lp.resolve_words(slots)
+            assert out.best_index == res0.best_index
+            if res0.best_index >= 0:
+                assert (out.best_cost, out.vx, out.vy, out.wz) == (res0.best_cost, res0.vx, res0.vy, res0.wz)
+            assert out.planner_state == res0.planner_state
+    finally:
+        for lp in ctxs:
+            lp.close()
