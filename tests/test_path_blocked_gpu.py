@@ -34,11 +34,13 @@ def test_matches_oracle_on_c2(radius):
         assert op == K.OPINION_PATH_BLOCKED_WAIT and flags.any()
 
 
+# DDDMR_BLOCKED_CASES=N widens the sweep for a soak run (default 12)
 def test_random_clouds_and_plans():
+    import os
     rng = np.random.default_rng(5)
     th = configs.bench_theory("C1")
     with LocalPlanner([th], max_points=50_000) as lp:
-        for case in range(12):
+        for case in range(int(os.environ.get("DDDMR_BLOCKED_CASES", "12"))):
             n = int(rng.choice([6, 50, 5000, 40000]))
             cloud = np.zeros((n, 4), np.float32)
             cloud[:, :3] = rng.uniform(-6, 6, (n, 3)) * np.array([1, 1, 0.2])
