@@ -339,6 +339,39 @@ const dddmr_theory_config* find_theory(const dddmr_rollout_ctx* ctx, const char*
   return nullptr;
 }
 
+// The points the collision critics look at around one pose, in the body frame: the 8 cuboid vertices (the min-max
+// critic tests their bounding box) AND the 8 corners of the region CollisionModel tests, { d : |d . a_i| <= h_i } around
+// the mean of the vertices with a_i, h_i from the edges e_i = v_i - v_0 (collision_model.cpp:85-115).  For a cuboid
+// that is a body-frame box that region is the cuboid; for any other vertex list the three slabs meet in the DUAL
+// parallelepiped, centre +- g_1 +- g_2 +- g_3, g_i = (e_j x e_k) |e_i|^2 / (2 det), which reaches beyond the vertices'
+// hull -- a tile / candidate range sized by the vertices alone never looks at the points in between (found by a soak).
+// A degenerate vertex list leaves the region unbounded: the corners then go to the 1 m search ball's box.
+void collision_extent_points(const dddmr_theory_config& c, double out[16][3]) {
+  double ctr[3] = {0, 0, 0}, e[3][3], g[3][3];
+  for (int k = 0; k < 8; ++k)
+    for (int a = 0; a < 3; ++a) { out[k][a] = c.cuboid[k][a]; ctr[a] += c.cuboid[k][a] / 8.0; }
+  for (int i = 0; i < 3; ++i)
+    for (int a = 0; a < 3; ++a) e[i][a] = (double)c.cuboid[i + 1][a] - (double)c.cuboid[0][a];
+  auto cross = [](const double* u, const double* v, double* w) {
+    w[0] = u[1] * v[2] - u[2] * v[1]; w[1] = u[2] * v[0] - u[0] * v[2]; w[2] = u[0] * v[1] - u[1] * v[0];
+  };
+  double cr[3][3];
+  cross(e[1], e[2], cr[0]); cross(e[2], e[0], cr[1]); cross(e[0], e[1], cr[2]);
+  const double det = e[0][0] * cr[0][0] + e[0][1] * cr[0][1] + e[0][2] * cr[0][2];
+  const bool ok = std::fabs(det) > 1e-12;
+  for (int i = 0; i < 3; ++i) {
+    const double n2 = e[i][0] * e[i][0] + e[i][1] * e[i][1] + e[i][2] * e[i][2];
+    for (int a = 0; a < 3; ++a) g[i][a] = ok ? cr[i][a] * n2 / (2.0 * det) : 0.0;
+  }
+  for (int corner = 0; corner < 8; ++corner)
+    for (int a = 0; a < 3; ++a) {
+      double v = ctr[a];
+      for (int i = 0; i < 3; ++i) v += ((corner >> i) & 1) ? g[i][a] : -g[i][a];
+      if (!ok) v = ((corner >> a) & 1) ? 1.0 : -1.0;
+      out[8 + corner][a] = std::max(-3.0, std::min(3.0, v));
+    }
+}
+
 // Extent of the local costmap tile: every cloud point that can be inside any
 // cuboid of any trajectory of this tick.  A pose stays within rho =
 // max speed * sim_time of base_link in the body xy-plane, a cuboid vertex
@@ -360,10 +393,12 @@ void tile_extent(const dddmr_theory_config& c, const Window& w, const double R[9
   }
   rho = rho * 1.001 + 0.01;  // float state rounding
   double rv = 0, vz0 = 1e30, vz1 = -1e30;
-  for (int k = 0; k < 8; ++k) {
-    rv = std::max(rv, std::hypot((double)c.cuboid[k][0], (double)c.cuboid[k][1]));
-    vz0 = std::min(vz0, (double)c.cuboid[k][2]);
-    vz1 = std::max(vz1, (double)c.cuboid[k][2]);
+  double ext[16][3];
+  collision_extent_points(c, ext);
+  for (int k = 0; k < 16; ++k) {
+    rv = std::max(rv, std::hypot(ext[k][0], ext[k][1]));
+    vz0 = std::min(vz0, ext[k][2]);
+    vz1 = std::max(vz1, ext[k][2]);
   }
   const double e = rho + rv;
   const double margin = 0.02;
@@ -924,12 +959,16 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   // A cuboid's AABB (clipped to the 2 m wide search ball) must not span more than
   // kRows cell rows: rows <= span / cell + 2.
   double diam = 0;
-  for (int a = 0; a < 8; ++a)
-    for (int b = a + 1; b < 8; ++b) {
-      const double dx = th->cuboid[a][0] - th->cuboid[b][0], dy = th->cuboid[a][1] - th->cuboid[b][1],
-                   dz = th->cuboid[a][2] - th->cuboid[b][2];
-      diam = std::max(diam, std::sqrt(dx * dx + dy * dy + dz * dz));
-    }
+  {
+    double ext[16][3];
+    collision_extent_points(*th, ext);
+    for (int a = 0; a < 16; ++a)
+      for (int b = a + 1; b < 16; ++b) {
+        const double dx = ext[a][0] - ext[b][0], dy = ext[a][1] - ext[b][1], dz = ext[a][2] - ext[b][2];
+        diam = std::max(diam, std::sqrt(dx * dx + dy * dy + dz * dz));
+      }
+    diam += 4e-4;     // the candidate range's margin on both sides (k_score phase D1)
+  }
   float cell = std::max(ctx->cell_size, (float)(std::min(diam, 2.0) * 1.001 / (kRows - 2)));
   float cell_z = cell;     // z cells do not grow with the x/y cells below
   // Big shards run many 256-lane workgroups per CU and are bound by how many (trajectory,
@@ -974,9 +1013,11 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   // inside the box is within max|vertex| of the pose, so a cuboid that lies inside the
   // search ball never does (the min-max critic always needs it).
   double vnorm = 0;
-  for (int v = 0; v < 8; ++v)
-    vnorm = std::max(vnorm, std::sqrt((double)th->cuboid[v][0] * th->cuboid[v][0] + (double)th->cuboid[v][1] * th->cuboid[v][1] +
-                                      (double)th->cuboid[v][2] * th->cuboid[v][2]));
+  {
+    double ext[16][3];       // (the corners of the box the collision critic derives count too)
+    collision_extent_points(*th, ext);
+    for (int v = 0; v < 16; ++v) vnorm = std::max(vnorm, std::sqrt(ext[v][0] * ext[v][0] + ext[v][1] * ext[v][1] + ext[v][2] * ext[v][2]));
+  }
   k.rec_pose = (vnorm >= 0.985 || k.want_minmax) ? 1 : 0;
   const int rec_words = rec_words_of(k.rec_pose != 0, k.want_minmax != 0);
   {
@@ -1171,7 +1212,7 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   int64_t* score_words = ctx->comm ? ctx->slots_dev + 2 * rank : nullptr;
   if (k.n_local > 0) {
     const int wgs = k.n_tiles;
-    const bool lean = !k.want_minmax && !k.rec_pose;
+    const bool lean = !k.want_minmax && !k.rec_pose && k.box_fast;
 #define DDDMR_LAUNCH_SCORE(T, L)                                                                                   \
   do { if (k.probe) DDDMR_LAUNCH_SCORE_P(T, L, true); else DDDMR_LAUNCH_SCORE_P(T, L, false); } while (0)
 #define DDDMR_LAUNCH_SCORE_P(T, L, P)                                                                              \

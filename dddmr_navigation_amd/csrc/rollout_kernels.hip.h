@@ -1091,9 +1091,9 @@ __device__ __forceinline__ void reduce_slots(const DevTick& k, const int lane, c
   }
 }
 
-// kLean: the common critic stack -- no min-max critic and no pair that needs the 1 m radius test
-// (the cuboid lies inside the search ball) -- as compile-time facts: the walk loses its radius /
-// min-max code and the records their optional words.
+// kLean: the common case -- no min-max critic, no pair that needs the 1 m radius test (the cuboid lies
+// inside the search ball) and a cuboid that is a body-frame box -- as compile-time facts: the walk loses its
+// radius / min-max code, the records their optional words, phase D1 its general-vertex-list path.
 // kProbe: the collision walk starts with a probe round (compile-time: as a run-time flag it cost the walk its
 // schedule -- 121 -> 107 VGPRs and +10 % time).
 template <int kScoreThreads, bool kLean, bool kProbe>
@@ -1110,6 +1110,7 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
   const int Qcap = tile * k.max_steps;
   const bool need_box = k.want_collision != 0, need_mm = !kLean && k.want_minmax != 0;
   const bool rec_pose = !kLean && k.rec_pose != 0;
+  const bool box_fast = kLean || k.box_fast != 0;      // (the lean variant is only launched for body-frame boxes)
   const int rec_words = rec_words_of(rec_pose, need_mm);
   const int mm_ofs = kRecBase + (rec_pose ? 3 : 0);
   size_t ofs = 0;
@@ -1235,7 +1236,7 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
           vmax2 = fmaxf(vmax2, ux * ux + uy * uy + uz * uz);
         }
       };
-      if (k.box_fast && !rec_pose) {
+      if (box_fast && !rec_pose) {
         // The cuboid is a box in the body frame (x back/front, y left/right, z bottom/top --
         // checked bit for bit on the host), so the 24 products L(i,c) * coordinate take only
         // 18 distinct values and the partial sums L(i,0) x + L(i,1) y only 12: same
@@ -1269,6 +1270,49 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
           world_vertex(vtx, wx, wy, wz);
         }
       }
+      // What the collision critic tests is { d : |d . a_i| <= h_i, i = 1..3 } around the mean of the 8 vertices, with
+      // a_i, h_i from the edges e_i = v_i - v_0 (collision_model.cpp:85-115).  For a body-frame box the e_i are
+      // orthogonal and that region is the cuboid itself, centre +- e_1/2 +- e_2/2 +- e_3/2.  For any other vertex list
+      // the three slabs meet in the DUAL parallelepiped, centre +- g_1 +- g_2 +- g_3 with g_i = (e_j x e_k) |e_i|^2 /
+      // (2 det[e_1 e_2 e_3]), which reaches beyond the vertices' bounding box -- in the soak scenario that found this by
+      // 3.3 cm, where a point collided in the reference and was never looked at here.  g_i bound the candidate cells
+      // (obx, oby) and the radius-skip flag below.
+      float obx, oby;      // extent of that region along world x and y
+      {
+        const float e1x = v[1][0] - v[0][0], e1y = v[1][1] - v[0][1], e1z = v[1][2] - v[0][2];
+        const float e2x = v[2][0] - v[0][0], e2y = v[2][1] - v[0][1], e2z = v[2][2] - v[0][2];
+        const float e3x = v[3][0] - v[0][0], e3y = v[3][1] - v[0][1], e3z = v[3][2] - v[0][2];
+        // ... and, where the 1 m radius test may matter, than the farthest corner of the tested region
+        auto far_corner = [&](float g1x, float g1y, float g1z, float g2x, float g2y, float g2z, float g3x, float g3y, float g3z) {
+          const float ox = ccx / 8.f - px, oy = ccy / 8.f - py, oz = ccz / 8.f - pz;
+#pragma unroll
+          for (int corner = 0; corner < 8; ++corner) {
+            const float a = (corner & 1) ? 1.0f : -1.0f, b = (corner & 2) ? 1.0f : -1.0f, c3 = (corner & 4) ? 1.0f : -1.0f;
+            const float ux = ox + a * g1x + b * g2x + c3 * g3x, uy = oy + a * g1y + b * g2y + c3 * g3y,
+                        uz = oz + a * g1z + b * g2z + c3 * g3z;
+            vmax2 = fmaxf(vmax2, ux * ux + uy * uy + uz * uz);
+          }
+        };
+        if (box_fast) {
+          obx = 0.5f * (fabsf(e1x) + fabsf(e2x) + fabsf(e3x));
+          oby = 0.5f * (fabsf(e1y) + fabsf(e2y) + fabsf(e3y));
+          if (rec_pose) far_corner(0.5f * e1x, 0.5f * e1y, 0.5f * e1z, 0.5f * e2x, 0.5f * e2y, 0.5f * e2z, 0.5f * e3x, 0.5f * e3y, 0.5f * e3z);
+        } else {
+          const float c1x = e2y * e3z - e2z * e3y, c1y = e2z * e3x - e2x * e3z, c1z = e2x * e3y - e2y * e3x;
+          const float c2x = e3y * e1z - e3z * e1y, c2y = e3z * e1x - e3x * e1z, c2z = e3x * e1y - e3y * e1x;
+          const float c3x = e1y * e2z - e1z * e2y, c3y = e1z * e2x - e1x * e2z, c3z = e1x * e2y - e1y * e2x;
+          const float det = e1x * c1x + e1y * c1y + e1z * c1z;
+          // (a degenerate vertex list makes the region unbounded: the 1 m search ball then is the only bound)
+          const float inv = fabsf(det) > 1e-12f ? 0.5f / det : 3.0e+30f;
+          const float s1 = (e1x * e1x + e1y * e1y + e1z * e1z) * inv, s2 = (e2x * e2x + e2y * e2y + e2z * e2z) * inv,
+                      s3 = (e3x * e3x + e3y * e3y + e3z * e3z) * inv;
+          obx = fabsf(c1x * s1) + fabsf(c2x * s2) + fabsf(c3x * s3);
+          oby = fabsf(c1y * s1) + fabsf(c2y * s2) + fabsf(c3y * s3);
+          if (rec_pose) far_corner(c1x * s1, c1y * s1, c1z * s1, c2x * s2, c2y * s2, c2z * s2, c3x * s3, c3y * s3, c3z * s3);
+        }
+        obx = obx * 1.00001f + 1e-4f;
+        oby = oby * 1.00001f + 1e-4f;
+      }
       float* r = rec + (size_t)q * rec_words;
       r[0] = ccx / 8.f; r[1] = ccy / 8.f; r[2] = ccz / 8.f;
       // The box axes and half extents (three square roots, nine divisions) are only needed by pairs that find
@@ -1280,9 +1324,13 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
         r[3 + 3 * a + 1] = v[a][1];
         r[3 + 3 * a + 2] = v[a][2];
       }
-      // candidate cells: cuboid AABB clipped to the 1 m search ball's AABB
-      const float lox = fmaxf(mnx, px - 1.0f), hix = fminf(mxx, px + 1.0f);
-      const float loy = fmaxf(mny, py - 1.0f), hiy = fminf(mxy, py + 1.0f);
+      // Candidate cells: the bounding box of what the critics test -- the region above for the collision critic, the
+      // vertices' own bounding box for the min-max critic -- clipped to the 1 m search ball's box, plus 0.1 mm + 1e-5
+      // of the extent for the float rounding of the reference's normalised axes (more cells never change a result; a
+      // missing one loses a collision).
+      const float ocx = ccx / 8.f, ocy = ccy / 8.f;
+      const float lox = fmaxf(fminf(mnx, ocx - obx), px - 1.0f), hix = fminf(fmaxf(mxx, ocx + obx), px + 1.0f);
+      const float loy = fmaxf(fminf(mny, ocy - oby), py - 1.0f), hiy = fminf(fmaxf(mxy, ocy + oby), py + 1.0f);
       int cx0 = (int)floorf((lox - k.gmin[0]) * k.inv_cell), cx1 = (int)floorf((hix - k.gmin[0]) * k.inv_cell);
       int cy0 = (int)floorf((loy - k.gmin[1]) * k.inv_cell), cy1 = (int)floorf((hiy - k.gmin[1]) * k.inv_cell);
       cx0 = max(cx0, 0); cy0 = max(cy0, 0);

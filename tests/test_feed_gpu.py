@@ -126,7 +126,7 @@ def test_random_scans_and_transforms(seed):
     """Random sensor mounts, robot poses (any yaw, ramps up to ~15 deg), crop windows and scan sizes: the same voxel
     set as the oracle's cbSensor restatement, centroids within 1e-5 m."""
     from scipy.spatial import cKDTree
-    rng = np.random.default_rng(500 + seed)
+    rng = np.random.default_rng(500 + seed + int(os.environ.get("DDDMR_SEED_BASE", "0")))
     cloud = scenes.cloud_c2()
     tbs = (float(rng.uniform(-0.3, 0.3)), float(rng.uniform(-0.2, 0.2)), float(rng.uniform(0.2, 0.9))) + \
         tuple(scenes.quat_from_rpy(float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-0.1, 0.1)), float(rng.uniform(-0.2, 0.2))))

@@ -168,7 +168,7 @@ def test_marking_capacity_and_state_errors():
 def test_random_marking_sequences(seed):
     """Randomised layer parameters, robot paths (position, small roll / pitch, height drift) and obstacles that come
     and go: every update's voxel set, counts, dGraph and lethal set against the oracle, as in the fixed sequences."""
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + int(os.environ.get("DDDMR_SEED_BASE", "0")))
     _, _, walls, corridor = _scene()
     res = float(rng.choice([0.05, 0.1]))
     cfg = marking.shipped_config(

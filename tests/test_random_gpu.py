@@ -90,6 +90,10 @@ def random_case(rng, permute_stack=False):
     return th, cloud, plan, tick
 
 
+# DDDMR_SEED_BASE shifts every seed of this file (a soak over scenarios the default sweep never sees)
+SEED_BASE = int(os.environ.get("DDDMR_SEED_BASE", "0"))
+
+
 # How often the tolerance branches of this file fire: written to
 # gpurun_out/parity_stats_random.json at the end of the module, quoted in DESIGN.md section 5.
 STATS = {"runs": 0, "runs_with_fragile_flip": 0, "runs_winner_differs_within_1e-6": 0,
@@ -119,7 +123,7 @@ def _last_argmin(costs):
 @pytest.mark.parametrize("permuted", [False, True], ids=["collision_first", "shuffled_stack"])
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DDDMR_RANDOM_SEEDS", "120"))))
 def test_random_scenario(seed, permuted):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + SEED_BASE)
     th, cloud, plan, tick = random_case(rng, permute_stack=permuted)
     with LocalPlanner([th], max_points=max(len(cloud), 16), max_steps=512) as lp:
         lp.set_cloud(cloud)
@@ -169,6 +173,23 @@ def test_random_scenario(seed, permuted):
         STATS["runs_winner_unchecked_after_flip"] += 1
 
 
+def test_collision_box_that_sticks_out_of_its_vertices():
+    """Found by a soak (scenario 102133): a jittered cuboid -- CollisionModel's box is the mean of the 8 vertices
+    +- half the edges v1-v0, v2-v0, v3-v0 (collision_model.cpp:85-115), which for a vertex list that is not a body-frame
+    box reaches beyond the vertices' own bounding box.  A cloud point in that sliver collides in the reference; the
+    candidate cells used to be taken from the vertices' bounding box and never looked at it."""
+    th, cloud, plan, tick = random_case(np.random.default_rng(102133), permute_stack=False)
+    with LocalPlanner([th], max_points=len(cloud), max_steps=512) as lp:
+        lp.set_cloud(cloud)
+        lp.setPlan(plan)
+        lp.tick("t", tick)
+        costs = lp.debug()[0].copy()
+    o = oracle.tick(th, cloud, plan, tick, n_threads=8, want_margin=True)
+    assert o.costs[38] == -1.0 and abs(o.min_margin[38]) > 5e-3          # a clear collision, 8.7 mm inside the box
+    assert costs[38] == -1.0
+    np.testing.assert_array_equal(costs < 0, o.costs < 0)
+
+
 # DDDMR_RANDOM_SHARD_SEEDS=N widens the sweep (default 12)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("DDDMR_RANDOM_SHARD_SEEDS", "12"))))
 def test_random_scenario_sharded_over_contexts(seed):
@@ -176,7 +197,7 @@ def test_random_scenario_sharded_over_contexts(seed):
     per-trajectory outputs tile the unsharded ones bit for bit, and the exact slot-vector resolve
     (dddmr_rollout_winner_words / _resolve_words: minimum cost as full doubles, equal costs -> highest index) yields
     the unsharded winner and command on every rank."""
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + seed + SEED_BASE)
     th, cloud, plan, tick = random_case(rng, permute_stack=bool(seed & 1))
     world = int(np.random.default_rng(7000 + seed).integers(2, 8))
     with LocalPlanner([th], max_points=max(len(cloud), 16), max_steps=512) as lp:
