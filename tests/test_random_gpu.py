@@ -18,6 +18,11 @@ os.environ["DDDMR_POISON"] = "1"
 TOL = 1e-4
 
 
+# DDDMR_RANDOM_WILD=1 (soak runs): the same generator with the extremes switched on -- vertex lists far from a box
+# (jitter up to 0.2 m), degenerate ones (a zero edge, a flat cuboid), tiny cuboids, 100k-point clouds, steep ramps
+WILD = os.environ.get("DDDMR_RANDOM_WILD", "0") not in ("", "0")
+
+
 def random_case(rng, permute_stack=False):
     kind = rng.choice(["dd", "omni", "rot"], p=[0.45, 0.4, 0.15])
     # cuboid: random box (sometimes long: corners beyond the 1 m ball), reference vertex order
@@ -31,6 +36,18 @@ def random_case(rng, permute_stack=False):
         # not a body-frame box: sheared / jittered vertices take the general vertex path
         # (the collision critic still derives its OBB from vertices 0, 1, 2, 3)
         cub = [tuple(float(c + d) for c, d in zip(v, rng.uniform(-0.05, 0.05, 3))) for v in cub]
+    if WILD:
+        # (own stream, seeded from the generator's state without drawing from it: the rest of the case stays as it is)
+        wr = np.random.default_rng(int(rng.bit_generator.state["state"]["state"]) & 0xFFFFFFFF)
+        u = wr.random()
+        if u < 0.25:
+            cub = [tuple(float(c + d) for c, d in zip(v, wr.uniform(-0.2, 0.2, 3))) for v in cub]
+        elif u < 0.30:
+            cub = list(cub); cub[1] = cub[0]                               # zero edge v1 - v0
+        elif u < 0.35:
+            cub = [(v[0], v[1], 0.2) for v in cub]                         # flat: zero edge v2 - v0
+        elif u < 0.45:
+            cub = [tuple(float(0.12 * c) for c in v) for v in cub]         # a 10 cm robot
     stack = [configs.critic(K.CRITIC_COLLISION if rng.random() < 0.8 else K.CRITIC_COLLISION_MIN_MAX)]
     if rng.random() < 0.2:
         stack.append(configs.critic(K.CRITIC_COLLISION_MIN_MAX))
@@ -64,12 +81,13 @@ def random_case(rng, permute_stack=False):
         th = configs.rotate_inplace_shipped("t", rotation_speed=float(rng.uniform(0.2, 0.8)), **common)
         twist = (0.0, 0.0, 0.0)
     # pose: anywhere, any attitude (ramps up to ~20 deg)
-    q = scenes.quat_from_rpy(rng.uniform(-0.35, 0.35), rng.uniform(-0.35, 0.35), rng.uniform(-math.pi, math.pi))
+    tilt = 0.8 if WILD else 0.35
+    q = scenes.quat_from_rpy(rng.uniform(-tilt, tilt), rng.uniform(-tilt, tilt), rng.uniform(-math.pi, math.pi))
     pos = rng.uniform(-30, 30, 3) * np.array([1, 1, 0.1])
     tick = scenes.tick_input(pose=tuple(pos) + q, twist=twist, allowed_max=(-1.0 if rng.random() < 0.7 else rng.uniform(0.2, 1.0)),
                              heading_deviation=rng.uniform(-1, 1))
     # cloud: clutter around the robot (global frame), a few walls, sometimes tiny
-    n = int(rng.choice([0, 3, 5, 200, 3000, 20000]))
+    n = int(rng.choice([0, 3, 5, 200, 3000, 20000] + ([100000] if WILD else [])))
     pts = rng.uniform(-5, 5, (n, 3)) * np.array([1, 1, 0.3]) + pos
     if n >= 200:
         wall = np.stack([np.full(400, pos[0] + rng.uniform(0.6, 2.5)), pos[1] + rng.uniform(-3, 3, 400),
