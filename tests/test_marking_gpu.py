@@ -178,12 +178,24 @@ def test_random_marking_sequences(seed):
         xy_resolution=res, height_resolution=res,
         inscribed_radius=float(rng.uniform(0.3, 0.6)), inflation_radius=float(rng.uniform(0.8, 1.6)),
         vertical_FOV_top=float(rng.choice([15.0, 20.0])), vertical_FOV_bottom=float(rng.choice([-15.0, -20.0])))
+    tilt = 0.04
+    if os.environ.get("DDDMR_RANDOM_WILD", "0") not in ("", "0"):
+        # soak runs: the layer's other parameters move too (own stream, seeded without drawing from rng)
+        wr = np.random.default_rng(int(rng.bit_generator.state["state"]["state"]) & 0xFFFFFFFF)
+        cfg.height_resolution = float(wr.choice([0.05, 0.1, 0.2]))
+        cfg.marking_height = float(wr.uniform(0.8, 2.5))
+        cfg.perception_window_size = float(wr.uniform(3.0, 8.0))
+        a0, a1 = float(wr.uniform(5.0, 60.0)), float(wr.uniform(120.0, 180.0))
+        cfg.scan_effective_positive_start, cfg.scan_effective_positive_end = a0, a1
+        cfg.scan_effective_negative_start, cfg.scan_effective_negative_end = -float(wr.uniform(5.0, 60.0)), -float(wr.uniform(120.0, 180.0))
+        cfg.vertical_FOV_top, cfg.vertical_FOV_bottom = float(wr.uniform(5.0, 30.0)), -float(wr.uniform(5.0, 30.0))
+        tilt = float(wr.choice([0.04, 0.15, 0.3]))
     static_map = walls if rng.random() < 0.5 else np.concatenate([walls, corridor])
     n_updates = 8
     xs = np.cumsum(rng.uniform(0.0, 0.4, n_updates))
     ys = np.cumsum(rng.uniform(-0.15, 0.15, n_updates))
     zs = np.cumsum(rng.uniform(-0.01, 0.02, n_updates))
-    rp = rng.uniform(-0.04, 0.04, (n_updates, 2))
+    rp = rng.uniform(-0.04, 0.04, (n_updates, 2)) * (tilt / 0.04)
     holes = [(float(rng.uniform(0.0, 5.0)), float(rng.uniform(-2.0, 2.0)), float(rng.uniform(0.6, 1.6)))
              if rng.random() < 0.5 else None for _ in range(n_updates)]
 
