@@ -251,3 +251,60 @@ def test_random_scenario_sharded_over_contexts(seed):
     finally:
         for lp in ctxs:
             lp.close()
+
+
+# DDDMR_RANDOM_SEQ_SEEDS=N widens the sweep (default 6)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DDDMR_RANDOM_SEQ_SEEDS", "6"))))
+def test_random_sequences_of_ticks(seed):
+    """State carried between ticks must never leak into a result: ONE context with three random theories, ten ticks
+    that switch theory at random, move the robot, replace the cloud or the prune plan now and then (load feedback
+    from a different theory / pose / cloud, the adaptive probe round, the triple-buffered cloud), each tick against the
+    oracle on exactly that tick's inputs."""
+    base = 1000 + seed + SEED_BASE
+    cases = [random_case(np.random.default_rng(base * 7 + i), permute_stack=bool((seed + i) & 1)) for i in range(3)]
+    theories = []
+    for i, c in enumerate(cases):
+        th = c[0]
+        th.name = f"t{i}".encode()
+        theories.append(th)
+    rng = np.random.default_rng(base + 55)
+    max_pts = max(max(len(c[1]) for c in cases), 16)
+    cloud, plan = cases[0][1], cases[0][2]
+    with LocalPlanner(theories, max_points=max_pts, max_steps=512) as lp:
+        lp.set_cloud(cloud)
+        lp.setPlan(plan)
+        for t in range(10):
+            i = int(rng.integers(0, 3))
+            th, _, _, tick = cases[i]
+            u = rng.random()
+            if u < 0.3:
+                cloud = cases[int(rng.integers(0, 3))][1]
+                if len(cloud) > 10 and rng.random() < 0.5:
+                    cloud = cloud[rng.random(len(cloud)) < 0.8]
+                lp.set_cloud(cloud)
+            elif u < 0.45:
+                plan = cases[int(rng.integers(0, 3))][2]
+                lp.setPlan(plan)
+            # the case's own tick input, the robot nudged along (the cloud and the plan stay where they are)
+            pose = np.array([tick.robot_pose[k] for k in range(7)], dtype=np.float64)
+            pose[:3] += rng.uniform(-0.3, 0.3, 3) * np.array([1.0, 1.0, 0.05])
+            tk = scenes.tick_input(pose=tuple(pose), twist=(tick.robot_twist[0], tick.robot_twist[1], tick.robot_twist[2]),
+                                   allowed_max=tick.allowed_max_linear_speed, heading_deviation=tick.heading_deviation)
+            res = lp.tick(f"t{i}", tk)
+            costs, steps, smp = (a.copy() for a in lp.debug())
+            n = res.n_samples
+            o = oracle.tick(th, cloud, plan, tk, n_threads=8, want_margin=True)
+            np.testing.assert_array_equal(steps[:n], o.steps)
+            np.testing.assert_array_equal(smp[:n], o.samples)
+            fragile = np.abs(o.min_margin) < TOL
+            neg = (costs[:n] < 0) | (o.costs < 0)
+            bad = neg & (costs[:n] != o.costs) & ~fragile
+            assert not bad.any(), (t, i, np.nonzero(bad)[0][:5], costs[:n][bad][:5], o.costs[bad][:5], o.min_margin[bad][:5])
+            both = (costs[:n] >= 0) & (o.costs >= 0)
+            if both.any():
+                assert float(np.max(np.abs(costs[:n][both] - o.costs[both]))) <= TOL
+            assert res.best_index == _last_argmin(costs[:n])
+            if not (neg & (costs[:n] != o.costs)).any():
+                assert res.planner_state == o.result.planner_state
+                if res.best_index != o.result.best_index:
+                    assert abs(costs[res.best_index] - o.costs[o.result.best_index]) <= 1e-6
