@@ -308,3 +308,44 @@ def test_random_sequences_of_ticks(seed):
                 assert res.planner_state == o.result.planner_state
                 if res.best_index != o.result.best_index:
                     assert abs(costs[res.best_index] - o.costs[o.result.best_index]) <= 1e-6
+
+
+# DDDMR_RANDOM_DEBUG_SEEDS=N widens the sweep (default 8)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DDDMR_RANDOM_DEBUG_SEEDS", "8"))))
+def test_random_scenario_debug_outputs(seed):
+    """The visualisation outputs of the random scenarios: `trajectory` / `accepted_trajectory` pose arrays
+    (local_planner.cpp:549-569, :461-470), the best trajectory's poses and cuboids (:472-478, Trajectory::getCuboid)
+    against the oracle's generateTrajectory, sample by sample."""
+    rng = np.random.default_rng(1000 + seed + SEED_BASE)
+    th, cloud, plan, tick = random_case(rng, permute_stack=bool(seed & 1))
+    with LocalPlanner([th], max_points=max(len(cloud), 16), max_steps=512) as lp:
+        lp.set_cloud(cloud)
+        lp.setPlan(plan)
+        res = lp.tick("t", tick)
+        costs, steps, smp = (a.copy() for a in lp.debug())
+        every = lp.pose_arrays()
+        accepted = lp.pose_arrays(accepted_only=True)
+        best = lp.best_poses() if res.best_index >= 0 else None
+        best_cub = lp.best_cuboids() if res.best_index >= 0 else None
+    n = res.n_samples
+    want_all, want_acc, per = [], [], {}
+    for i in range(n):
+        if steps[i] <= 0:
+            continue
+        ref, ref_cub, _ = oracle.generate(th, tick, smp[i], capacity=1024)
+        assert len(ref) == steps[i]
+        want_all.append(ref)
+        if costs[i] >= 0:                      # (the engine's own verdicts: fragile flips are test_random_scenario's business)
+            want_acc.append(ref)
+        if i == res.best_index:
+            per = dict(ref=ref, cub=ref_cub)
+    assert len(every) == int(steps[:n][steps[:n] > 0].sum())
+    if want_all:
+        np.testing.assert_allclose(every, np.concatenate(want_all), atol=1e-5)
+    assert len(accepted) == sum(len(w) for w in want_acc)
+    if want_acc:
+        np.testing.assert_allclose(accepted, np.concatenate(want_acc), atol=1e-5)
+    if res.best_index >= 0:
+        np.testing.assert_allclose(best, per["ref"], atol=1e-5)
+        assert best_cub.shape == per["cub"].shape
+        np.testing.assert_allclose(best_cub, per["cub"], atol=1e-5)
