@@ -145,3 +145,33 @@ def test_random_scans_and_transforms(seed):
         d, idx = cKDTree(ref[:, :3]).query(got[:, :3])
         assert d.max() <= 1e-5
         assert len(np.unique(idx)) == len(ref)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("DDDMR_FEED_SEEDS", "3"))))
+def test_random_stitched_scan_sequences(seed):
+    """Random stitcher depths over a sequence of scans of random sizes, the robot moving between callbacks: the
+    observation is always the feed of the last N raw scans through the NEWEST transforms."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(900 + seed + int(os.environ.get("DDDMR_SEED_BASE", "0")))
+    cloud = scenes.cloud_c2()
+    depth = int(rng.integers(1, 6))
+    tbs = (float(rng.uniform(-0.2, 0.2)), 0.0, float(rng.uniform(0.3, 0.8))) + \
+        tuple(scenes.quat_from_rpy(0.0, float(rng.uniform(-0.05, 0.05)), float(rng.uniform(-0.1, 0.1))))
+    window, height = float(rng.uniform(3.0, 10.0)), float(rng.uniform(0.8, 2.2))
+    raw = []
+    with LocalPlanner([configs.bench_theory("C2")], max_points=150_000) as lp:
+        lp.set_stitcher(depth)
+        x = y = yaw = 0.0
+        for i in range(7):
+            x += float(rng.uniform(0.0, 0.4)); y += float(rng.uniform(-0.1, 0.1)); yaw += float(rng.uniform(-0.1, 0.1))
+            tgb = (x, y, 0.0) + tuple(scenes.quat_from_rpy(float(rng.uniform(-0.03, 0.03)), float(rng.uniform(-0.03, 0.03)), yaw))
+            scan = scenes.lidar_scan(cloud, sensor_xyz=(x, y, tbs[2]), seed=int(rng.integers(1 << 20)))
+            scan = scan[rng.permutation(len(scan))[: int(rng.choice([len(scan), len(scan) // 2, 300]))]]
+            raw.append(scan)
+            n = lp.set_scan(scan, tbs, tgb, window, height)
+            got = lp.get_cloud()[:, :3]
+            ref = oracle.feed(np.concatenate(raw[max(0, len(raw) - depth):]), tbs, tgb, window, height)
+            assert n == len(ref) == len(got)
+            if n:
+                d, idx = cKDTree(ref[:, :3]).query(got)
+                assert d.max() <= 1e-5 and len(np.unique(idx)) == len(ref)
