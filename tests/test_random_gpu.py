@@ -23,7 +23,8 @@ TOL = 1e-4
 WILD = os.environ.get("DDDMR_RANDOM_WILD", "0") not in ("", "0")
 
 
-def random_case(rng, permute_stack=False):
+def random_case(rng, permute_stack=False, wild=None):
+    WILD = globals()["WILD"] if wild is None else wild
     kind = rng.choice(["dd", "omni", "rot"], p=[0.45, 0.4, 0.15])
     # cuboid: random box (sometimes long: corners beyond the 1 m ball), reference vertex order
     lx0, lx1 = -rng.uniform(0.1, 0.9), rng.uniform(0.2, 1.3 if rng.random() < 0.3 else 0.7)
@@ -67,6 +68,23 @@ def random_case(rng, permute_stack=False):
     sim_time = float(rng.uniform(1.0, 4.0))
     common = dict(sim_time=sim_time, sim_granularity=float(rng.choice([0.05, 0.1])),
                   angular_sim_granularity=float(rng.choice([0.025, 0.05])), critics=stack, cuboid=cub)
+    extra = {}
+    if WILD and kind != "rot":
+        # the dynamic window's other inputs (dd_simple...cpp:236-295, omni_simple...cpp:260-332): acceleration limits,
+        # deceleration ratio, controller frequency, minimum speeds, the motor-shaft constraint (explicit sample list)
+        wr2 = np.random.default_rng((int(rng.bit_generator.state["state"]["state"]) >> 7) & 0xFFFFFFFF)
+        extra = dict(acc_lim_x=float(wr2.uniform(0.3, 3.0)), acc_lim_theta=float(wr2.uniform(0.5, 4.0)),
+                     deceleration_ratio=float(wr2.uniform(1.0, 5.0)), controller_frequency=float(wr2.choice([5.0, 10.0, 20.0])),
+                     min_vel_theta=float(wr2.uniform(0.0, 0.3)))
+        if kind == "dd":
+            extra.update(min_vel_x=float(wr2.uniform(0.0, 0.3)))
+            if wr2.random() < 0.4:
+                extra.update(use_motor_constraint=1, max_motor_shaft_rpm=float(wr2.uniform(30.0, 200.0)), gear_ratio=1.0,
+                             wheel_diameter=float(wr2.uniform(0.1, 0.3)), robot_radius=float(wr2.uniform(0.15, 0.4)))
+        else:
+            extra.update(acc_lim_y=float(wr2.uniform(0.3, 3.0)), min_vel_trans=float(wr2.uniform(0.0, 0.3)),
+                         max_vel_trans=float(wr2.uniform(0.5, 1.5)))
+    common.update(extra)
     if kind == "dd":
         th = configs.dd_simple_shipped(name="t", linear_x_sample=float(rng.integers(2, 9)),
                                        angular_z_sample=float(rng.integers(2, 14)), max_vel_x=float(rng.uniform(0.5, 1.5)),
@@ -196,7 +214,7 @@ def test_collision_box_that_sticks_out_of_its_vertices():
     +- half the edges v1-v0, v2-v0, v3-v0 (collision_model.cpp:85-115), which for a vertex list that is not a body-frame
     box reaches beyond the vertices' own bounding box.  A cloud point in that sliver collides in the reference; the
     candidate cells used to be taken from the vertices' bounding box and never looked at it."""
-    th, cloud, plan, tick = random_case(np.random.default_rng(102133), permute_stack=False)
+    th, cloud, plan, tick = random_case(np.random.default_rng(102133), permute_stack=False, wild=False)
     with LocalPlanner([th], max_points=len(cloud), max_steps=512) as lp:
         lp.set_cloud(cloud)
         lp.setPlan(plan)
