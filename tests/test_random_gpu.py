@@ -21,6 +21,9 @@ TOL = 1e-4
 # DDDMR_RANDOM_WILD=1 (soak runs): the same generator with the extremes switched on -- vertex lists far from a box
 # (jitter up to 0.2 m), degenerate ones (a zero edge, a flat cuboid), tiny cuboids, 100k-point clouds, steep ramps
 WILD = os.environ.get("DDDMR_RANDOM_WILD", "0") not in ("", "0")
+# DDDMR_RANDOM_SCALE=k multiplies the sample counts per axis (k = 4: up to ~13 000 samples, shards of several rounds
+# of k_score workgroups -- the default scenarios all fit one round)
+SCALE = int(os.environ.get("DDDMR_RANDOM_SCALE", "1"))
 
 
 def random_case(rng, permute_stack=False, wild=None):
@@ -86,13 +89,14 @@ def random_case(rng, permute_stack=False, wild=None):
                          max_vel_trans=float(wr2.uniform(0.5, 1.5)))
     common.update(extra)
     if kind == "dd":
-        th = configs.dd_simple_shipped(name="t", linear_x_sample=float(rng.integers(2, 9)),
-                                       angular_z_sample=float(rng.integers(2, 14)), max_vel_x=float(rng.uniform(0.5, 1.5)),
+        th = configs.dd_simple_shipped(name="t", linear_x_sample=float(rng.integers(2, 9) * SCALE),
+                                       angular_z_sample=float(rng.integers(2, 14) * SCALE), max_vel_x=float(rng.uniform(0.5, 1.5)),
                                        max_vel_theta=float(rng.uniform(0.3, 1.0)), **common)
         twist = (rng.uniform(0.0, 1.0), 0.0, rng.uniform(-0.3, 0.3))
     elif kind == "omni":
-        th = configs.omni_simple_shipped(name="t", linear_x_sample=float(rng.integers(2, 6)),
-                                         linear_y_sample=float(rng.integers(2, 6)), angular_z_sample=float(rng.integers(2, 9)), **common)
+        th = configs.omni_simple_shipped(name="t", linear_x_sample=float(rng.integers(2, 6) * SCALE),
+                                         linear_y_sample=float(rng.integers(2, 6) * SCALE),
+                                         angular_z_sample=float(rng.integers(2, 9) * SCALE), **common)
         twist = (rng.uniform(-0.5, 0.8), rng.uniform(-0.4, 0.4), rng.uniform(-0.3, 0.3))
     else:
         common.pop("sim_time")
