@@ -58,3 +58,37 @@ def test_comm_init_checks_the_shard():
         assert e.value.code == K.ERR_BAD_ARG
         with pytest.raises(RolloutError):
             lp.comm_init(lp.comm_unique_id(), 1, 3)            # context's world is 2
+
+
+import os
+
+
+# DDDMR_COMM_SEEDS=N widens the sweep (default 6)
+def test_one_rank_communicator_on_random_scenarios():
+    """The random scenarios of tests/test_random_gpu.py through k_score -> ncclAllReduce -> k_resolve (a 1-rank
+    communicator, created once: RCCL communicators are not cheap): what the tick delivers must be what the plain tick
+    of a second context delivers, field by field."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_random_gpu import random_case
+    n = int(os.environ.get("DDDMR_COMM_SEEDS", "6"))
+    cases = [random_case(np.random.default_rng(4000 + s + int(os.environ.get("DDDMR_SEED_BASE", "0"))), permute_stack=bool(s & 1))
+             for s in range(n)]
+    for i, c in enumerate(cases):
+        c[0].name = f"t{i % 8}".encode()
+    for g in range(0, n, 8):                                   # a context holds a handful of theories
+        group = cases[g:g + 8]
+        theories = [c[0] for c in group]
+        max_pts = max(max(len(c[1]) for c in group), 16)
+        with LocalPlanner(theories, max_points=max_pts, max_steps=512) as a, \
+                LocalPlanner(theories, max_points=max_pts, max_steps=512) as b:
+            b.comm_init(b.comm_unique_id(), 0, 1)
+            for th, cloud, plan, tick in group:
+                for lp in (a, b):
+                    lp.set_cloud(cloud)
+                    lp.setPlan(plan)
+                name = th.name.decode()
+                for _ in range(2):
+                    ra, rb = a.tick(name, tick), b.tick(name, tick)
+                    assert _fields(ra) == _fields(rb)
+                    np.testing.assert_array_equal(a.debug()[0], b.debug()[0])
