@@ -130,6 +130,8 @@ struct MarkCounters {         // device counters of one update (copied back for 
   uint32_t n_clusters, n_marked, n_in_window, n_cleared, n_alive, pool_used, overflow, n_groups2, n_groups3, n_clusters_kept;
   uint32_t n_removed;
   uint32_t n_dup;   // clusters of this update that found their voxel already claimed by another one (marking_fix_ties)
+  uint32_t n_new_keys;   // voxels that entered the store for the first time in this update (store garbage collection)
+  uint32_t n_rehashed;   // alive markings moved by this update's garbage collection
 };
 
 // isinLidarObservation (:682-746).  The reference builds a rotation that turns the x axis onto the viewing
@@ -509,6 +511,7 @@ __global__ __launch_bounds__(64) void k_mk_slots(MarkParams k, const MarkCounter
   bool found = false;
   for (uint32_t probe = 0; probe <= k.table_mask; ++probe) {
     const unsigned long long prev = atomicCAS(&s.keys[slot], 0ull, key);
+    if (prev == 0ull) atomicAdd(&cnt->n_new_keys, 1u);
     if (prev == 0ull || prev == key) { found = true; break; }
     slot = (slot + 1) & k.table_mask;
   }
@@ -588,6 +591,27 @@ __global__ __launch_bounds__(256) void k_mk_finish(MarkParams k, MarkStore s, Ma
   if (slot > k.table_mask) return;
   s.owner[slot] = 0ull;
   if (s.alive[slot]) s.alive_list[atomicAdd(&cnt->n_alive, 1u)] = slot;      // next update's selfClear walks this list
+}
+// Store garbage collection.  A voxel whose marking was cleared keeps its key (the reference's marking_[x][y][z] entry
+// stays too, with has_pc false: selfClear skips it, addPCPtr overwrites it), so a robot that keeps moving fills the
+// table with keys nothing reads any more.  When half the table is used the alive markings move to a fresh table;
+// the dropped keys change nothing the reference can observe.  One lane per old slot; the new alive list is built
+// on the way (its order is irrelevant: selfClear treats every marking on its own).
+__global__ __launch_bounds__(256) void k_mk_rehash(uint32_t table_mask, MarkStore s, unsigned long long* __restrict__ keys_new,
+                                                   uint32_t* __restrict__ alive_new, uint32_t* __restrict__ pts_ofs_new,
+                                                   uint32_t* __restrict__ pts_n_new, MarkCounters* __restrict__ cnt) {
+  const uint32_t slot = blockIdx.x * 256 + threadIdx.x;
+  if (slot > table_mask || !s.alive[slot]) return;
+  const unsigned long long key = s.keys[slot];
+  uint32_t ns = mk_hash(key) & table_mask;
+  for (uint32_t probe = 0; probe <= table_mask; ++probe) {          // (alive markings are fewer than slots: always ends)
+    if (atomicCAS(&keys_new[ns], 0ull, key) == 0ull) break;
+    ns = (ns + 1) & table_mask;
+  }
+  alive_new[ns] = 1;
+  pts_ofs_new[ns] = s.pts_ofs[slot];
+  pts_n_new[ns] = s.pts_n[slot];
+  s.alive_list[atomicAdd(&cnt->n_rehashed, 1u)] = ns;
 }
 // pool compaction: generator points of the alive markings move to the front of the other pool buffer
 __global__ __launch_bounds__(256) void k_mk_compact_sizes(uint32_t table, MarkStore s, uint32_t* __restrict__ sizes) {

@@ -26,7 +26,10 @@ struct MarkingState {
   float4* obs_copy[2] = {nullptr, nullptr};
   MarkStore store{};
   float4* pool_alt = nullptr;
-  uint32_t pool_used_host = 0, n_alive_host = 0;
+  // second set of the per-slot arrays for the store's garbage collection (k_mk_rehash)
+  unsigned long long* keys_alt = nullptr;
+  uint32_t *alive_alt = nullptr, *pts_ofs_alt = nullptr, *pts_n_alt = nullptr;
+  uint32_t pool_used_host = 0, n_alive_host = 0, keys_used_host = 0;
   // scratch of one update (sized for max_obs)
   uint2* gslot = nullptr;
   uint32_t* parent = nullptr;
@@ -64,7 +67,7 @@ void marking_free(MarkingState* m) {
   if (!m) return;
   void* p[] = {m->ground_pts, m->map_pts, m->obs_copy[0], m->obs_copy[1], m->store.keys, m->store.alive, m->store.pts_ofs,
                m->store.pts_n, m->store.removed_seq, m->store.owner, m->store.alive_list, m->store.removed_list, m->store.fov_flag,
-               m->store.pool, m->pool_alt, m->store.dgraph, m->store.lethal,
+               m->store.pool, m->pool_alt, m->store.dgraph, m->store.lethal, m->keys_alt, m->alive_alt, m->pts_ofs_alt, m->pts_n_alt,
                m->gslot, m->parent, m->keys_a, m->keys_b, m->keys1, m->vals_a, m->vals_b, m->flags, m->incl, m->cid_incl, m->ds,
                m->proj, m->gen, m->ds_first, m->pool_ofs, m->compact_sizes, m->compact_ofs, m->cl.start, m->cl.size, m->cl.centroid,
                m->cl.state, m->cl.ds_count, m->cl.gen_first, m->cl.gen_count, m->cl.slot, m->cl.vkey, m->counters, m->n_groups,
@@ -297,6 +300,10 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     HIPCHK(ctx, hipMalloc(&s.fov_flag, (size_t)table * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&s.pool, (size_t)m->pool_cap * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&m->pool_alt, (size_t)m->pool_cap * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&m->keys_alt, (size_t)table * sizeof(unsigned long long)));
+    HIPCHK(ctx, hipMalloc(&m->alive_alt, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->pts_ofs_alt, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->pts_n_alt, (size_t)table * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&s.dgraph, ((size_t)n_ground + 1) * sizeof(double)));
     HIPCHK(ctx, hipMalloc(&s.lethal, (size_t)n_ground + 1));
     HIPCHK(ctx, hipMalloc(&m->gslot, N * sizeof(uint2)));
@@ -366,6 +373,7 @@ int marking_reset_locked(dddmr_rollout_ctx* ctx) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
   m->pool_used_host = 0;
   m->n_alive_host = 0;
+  m->keys_used_host = 0;
   // (pcl_msg_gbl_ is untouched by resetdGraph: the previous observation stays)
   return DDDMR_OK;
 }
@@ -445,6 +453,22 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
   zero.pool_used = m->pool_used_host;
   HIPCHK(ctx, hipMemcpyAsync(m->counters, &zero, sizeof(zero), hipMemcpyHostToDevice, st));   // (pageable source: copied before return)
   HIPCHK(ctx, hipEventRecord(m->e0, st));
+
+  // ---- store garbage collection when half the table holds keys and a good part of them is dead ----
+  if (m->keys_used_host > m->table / 2 && m->keys_used_host > m->n_alive_host + m->table / 8) {
+    const size_t t = m->table;
+    HIPCHK(ctx, hipMemsetAsync(m->keys_alt, 0, t * sizeof(unsigned long long), st));
+    HIPCHK(ctx, hipMemsetAsync(m->alive_alt, 0, t * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(m->pts_ofs_alt, 0, t * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(m->pts_n_alt, 0, t * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(k_mk_rehash, dim3((m->table + 255) / 256), dim3(256), 0, st, m->table - 1, s, m->keys_alt, m->alive_alt,
+                       m->pts_ofs_alt, m->pts_n_alt, m->counters);
+    std::swap(s.keys, m->keys_alt);
+    std::swap(s.alive, m->alive_alt);
+    std::swap(s.pts_ofs, m->pts_ofs_alt);
+    std::swap(s.pts_n, m->pts_n_alt);
+    m->keys_used_host = m->n_alive_host;
+  }
 
   // ---- pool compaction when half of it is garbage-or-used ----
   if (m->pool_used_host > m->pool_cap / 2) {
@@ -538,6 +562,7 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
   HIPCHK(ctx, hipGetLastError());
   m->pool_used_host = out.pool_used;
   m->n_alive_host = out.n_alive;
+  m->keys_used_host += out.n_new_keys;
   if (out.n_dup > 0 && !out.overflow) {
     const int rc = marking_fix_ties(ctx, m, k, s, out);
     if (rc != DDDMR_OK) return rc;

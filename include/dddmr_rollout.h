@@ -386,7 +386,9 @@ typedef struct {
   int32_t reserved;
   double segmentation_ignore_ratio;
   double inscribed_radius, inflation_radius, max_obstacle_distance;
-  uint32_t max_markings;        /* capacity of the persistent store (alive + cleared-but-not-reused slots) */
+  uint32_t max_markings;        /* slots of the persistent store; size it for about twice the markings alive at a time:
+                                   cleared voxels keep their slot until the store's garbage collection drops them
+                                   (it runs when half the slots hold a key) */
   uint32_t max_cluster_points;  /* capacity of the pool of stored cluster points (0.2 m downsampled) */
 } dddmr_marking_config;
 

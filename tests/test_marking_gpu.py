@@ -106,6 +106,19 @@ def test_pool_compaction_keeps_the_store_identical():
     assert totals["marked"] > 5000 and final[0] > 1000
 
 
+def test_store_garbage_collection_keeps_the_store_identical():
+    """A table of 16384 slots for ~8000 alive markings: voxels whose marking was cleared keep their key, so the table
+    passes half full within a few updates of a moving robot and the garbage collection (alive markings move to a fresh
+    table, dead keys are dropped: the reference's entries with has_pc false, which nothing reads) runs several times
+    -- results must not move, and the layer must not report a full table."""
+    _, _, walls, _ = _scene()
+    cfg = marking.shipped_config(max_markings=1 << 14)
+    poses = lambda k: (0.35 * k, 0.0, 0.0, 0, 0, 0, 1)
+    scene_of = lambda k, cloud: cloud if k % 3 else cloud[np.hypot(cloud[:, 0] - 0.35 * k - 1.5, cloud[:, 1]) > 1.3]
+    totals, final = _run_sequence(cfg, walls, poses, scene_of, n_updates=16)
+    assert totals["marked"] > 16384 and totals["cleared"] > 3000
+
+
 def test_coarse_clusters_static_map_and_tilted_robot():
     """Tolerance 0.25 / min cluster size 3 (large wall clusters -> long summation chains), static-map
     rejection on (segmentation_ignore_ratio 0.5, the corridor walls are the static map), robot pitched and
@@ -219,3 +232,20 @@ def teardown_module(module):
     with open(os.path.join(out, "parity_stats_marking.json"), "w") as f:
         json.dump(STATS, f, indent=1)
     print("\n[parity stats, marking layer]", STATS)
+
+
+def test_long_sequence_with_many_compactions():
+    """A long drive up and down the corridor with obstacles that come and go and a pool barely larger than what the
+    alive markings need (compaction every few updates): the store must stay identical to the oracle's all the way
+    (DDDMR_MARKING_LONG=N updates, default 24)."""
+    _, _, walls, _ = _scene()
+    n = int(os.environ.get("DDDMR_MARKING_LONG", "24"))
+    cfg = marking.shipped_config(max_cluster_points=150000)
+    poses = lambda k: (3.0 * math.sin(0.11 * k), 0.4 * math.sin(0.05 * k), 0.0) + tuple(scenes.quat_from_rpy(0.0, 0.0, 0.0))
+
+    def scene_of(k, cloud):
+        cx = 2.5 * math.sin(0.07 * k + 1.0)
+        return cloud if (k // 5) % 2 == 0 else cloud[np.hypot(cloud[:, 0] - cx, cloud[:, 1]) > 1.2]
+
+    totals, final = _run_sequence(cfg, walls, poses, scene_of, n_updates=n, fragile_tol=1e-5)
+    assert totals["marked"] > 1000 and totals["cleared"] > 100
