@@ -103,3 +103,56 @@ def test_small_observation_returns_early():
     mo = oracle.MarkingOracle(cfg, marking.ground_lattice(half=3.0), np.zeros((0, 3), np.float32))
     st = mo.update(_blob(0.0, 2.0)[:5], T_BS, T_GB)
     assert (st.n_observation, st.n_clusters, st.n_marked, st.n_alive) == (0, 0, 0, 0)
+
+
+def test_clusters_are_the_connected_components_of_the_tolerance_graph():
+    """pcl::EuclideanClusterExtraction restated in the oracle, against an independent construction: the connected
+    components (scipy) of the graph that joins points closer than the tolerance (float squared distance, strict <
+    like FLANN's radius search), kept when they have at least min_cluster_size points."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(3)
+    ground = marking.ground_lattice(half=1.0, spacing=0.5, seed=1) + np.array([100.0, 100.0, 0.0], np.float32)   # far away
+    for case in range(8):
+        tol = float(rng.choice([0.1, 0.15, 0.25]))
+        mn = int(rng.choice([1, 3, 5]))
+        n = int(rng.choice([200, 1500, 5000]))
+        pts = (rng.uniform(-4, 4, (n, 3)) * np.array([1, 1, 0.25]) + np.array([0, 0, 0.6])).astype(np.float32)
+        pts = np.concatenate([pts, np.stack([np.full(300, 2.0), np.linspace(-3, 3, 300), rng.uniform(0.2, 1.5, 300)], 1).astype(np.float32)])
+        cfg = marking.shipped_config(euclidean_cluster_extraction_tolerance=tol, euclidean_cluster_extraction_min_cluster_size=mn)
+        mo = oracle.MarkingOracle(cfg, ground, np.zeros((0, 3), np.float32))
+        st = mo.update(pts, T_BS, T_GB)
+        pairs = cKDTree(pts.astype(np.float64)).query_pairs(tol * 1.001, output_type="ndarray")
+        d = pts[pairs[:, 0]] - pts[pairs[:, 1]]                                  # float32, as the kd-tree computes it
+        d2 = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+        keep = d2 < np.float32(tol * tol)
+        pairs = pairs[keep]
+        g = coo_matrix((np.ones(len(pairs)), (pairs[:, 0], pairs[:, 1])), shape=(len(pts), len(pts)))
+        _, lab = connected_components(g, directed=False)
+        sizes = np.bincount(lab)
+        assert st.n_clusters == int((sizes >= mn).sum()), (case, tol, mn, n)
+
+
+def test_dgraph_is_the_distance_to_the_marked_obstacles_within_a_voxel():
+    """computeMinDistanceFromObstacle2GroundNodes, checked from the outside: with the robot level at the origin the
+    generator points are 0.1 m voxel centroids of the obstacle points projected on z = 0, so a ground node's dGraph
+    value can differ from its xy distance to the nearest RAW obstacle point by at most a voxel diagonal, nodes well
+    inside the inflation radius must have a value and nodes well outside must keep 9999; lethal = within the
+    inscribed radius (same band)."""
+    rng = np.random.default_rng(8)
+    cfg = marking.shipped_config(euclidean_cluster_extraction_tolerance=0.25, inscribed_radius=0.4, inflation_radius=1.2)
+    ground = marking.ground_lattice(half=6.0, spacing=0.2, seed=2)
+    mo = oracle.MarkingOracle(cfg, ground, np.zeros((0, 3), np.float32))
+    centres = [(float(r * math.cos(a)), float(r * math.sin(a))) for r, a in
+               zip(rng.uniform(1.5, 4.5, 9), rng.uniform(math.radians(40), math.radians(170), 9) * rng.choice([-1, 1], 9))]
+    obs = np.concatenate([_blob(cx, cy) for cx, cy in centres])
+    st = mo.update(obs, T_BS, T_GB)
+    assert st.n_marked == st.n_clusters > 0                      # all in the sensor's view, none on the ground
+    dg, lethal = mo.dgraph()[:len(ground)], mo.lethal()[:len(ground)]
+    raw = np.min(np.hypot(ground[:, None, 0] - obs[None, :, 0], ground[:, None, 1] - obs[None, :, 1]), axis=1)
+    band = 0.1 * math.sqrt(2.0) + 0.05                           # voxel diagonal + the z the 3-D radius search sees
+    has = dg < 9999.0
+    assert has[raw < cfg.inflation_radius - band].all() and not has[raw > cfg.inflation_radius + band].any()
+    assert np.max(np.abs(dg[has] - raw[has])) <= band
+    assert lethal[raw < cfg.inscribed_radius - band].all() and not lethal[raw > cfg.inscribed_radius + band].any()
