@@ -338,3 +338,48 @@ def test_path_blocked_known_answers():
     d2 = (d2 + d[..., 2] * d[..., 2]).astype(np.float32)
     want = (d2 < np.float32(r * r)).any(axis=1) & (plan[:, 3] >= 0)
     np.testing.assert_array_equal(flags, want)
+
+
+def test_collision_verdicts_against_an_independent_numpy_box_test():
+    """CollisionModel (collision_model.cpp:51-148) restated in the oracle, against numpy: for every pose of every
+    trajectory the box is the mean of the 8 transformed vertices, axes / half extents from the edges v1-v0, v2-v0,
+    v3-v0; a trajectory collides when a cloud point within 1 m of a pose lies inside that pose's box.  Jittered
+    vertex lists included (the box then is NOT the vertices' hull).  Verdicts whose margin is below 1e-4 are skipped."""
+    rng = np.random.default_rng(12)
+    checked = collided = 0
+    for case in range(6):
+        named = {"flb": (0.4, 0.3, 0.0), "frb": (0.4, -0.3, 0.0), "flt": (0.4, 0.3, 0.6), "frt": (0.4, -0.3, 0.6),
+                 "blb": (-0.3, 0.3, 0.0), "brb": (-0.3, -0.3, 0.0), "blt": (-0.3, 0.3, 0.6), "brt": (-0.3, -0.3, 0.6)}
+        cub = configs.cuboid_vertices(named)
+        if case % 2:
+            cub = [tuple(float(c + d) for c, d in zip(v, rng.uniform(-0.06, 0.06, 3))) for v in cub]
+        th = configs.dd_simple_shipped(name="t", critics=[configs.critic(K.CRITIC_COLLISION)], cuboid=cub,
+                                       linear_x_sample=4.0, angular_z_sample=7.0, sim_time=2.5)
+        pose = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)), 0.0) + scenes.quat_from_rpy(0.05, -0.04, float(rng.uniform(-3, 3)))
+        tick = scenes.tick_input(pose=pose, twist=(0.5, 0.0, 0.1))
+        pts = (rng.uniform(-3.5, 3.5, (60, 3)) * np.array([1, 1, 0.15]) + np.array([pose[0], pose[1], 0.3])).astype(np.float32)
+        cloud = np.zeros((len(pts), 4), np.float32)
+        cloud[:, :3] = pts
+        o = oracle.tick(th, cloud, np.zeros((0, 7)), tick, n_threads=4, want_margin=True)
+        for i in range(len(o.costs)):
+            if o.steps[i] <= 0 or abs(o.min_margin[i]) < 1e-4:
+                continue
+            poses, cubs, _ = oracle.generate(th, tick, o.samples[i])
+            hit = False
+            for s in range(len(poses)):
+                v = cubs[s].astype(np.float32)
+                c = v.sum(0) / np.float32(8)
+                near = pts[np.linalg.norm(pts - poses[s, :3].astype(np.float32), axis=1) < 1.0]
+                if not len(near):
+                    continue
+                inside = np.ones(len(near), bool)
+                for e in (v[1] - v[0], v[2] - v[0], v[3] - v[0]):
+                    ln = np.linalg.norm(e)
+                    inside &= np.abs((near - c) @ (e / ln)) <= ln / 2
+                if inside.any():
+                    hit = True
+                    break
+            assert hit == (o.costs[i] < 0), (case, i, o.costs[i], o.min_margin[i])
+            checked += 1
+            collided += int(hit)
+    assert checked > 100 and 5 < collided < checked - 5
