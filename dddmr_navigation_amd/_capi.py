@@ -198,12 +198,16 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_comm_unique_id",
     "dddmr_rollout_comm_init",
     "dddmr_rollout_comm_destroy",
+    "dddmr_rollout_comm_ranks",
+    "dddmr_rollout_comm_loopback",
+    "dddmr_rollout_comm_loopback_set_peer",
     "dddmr_rollout_marking_create",
     "dddmr_rollout_marking_update",
     "dddmr_rollout_marking_reset",
     "dddmr_rollout_marking_get_voxels",
     "dddmr_rollout_marking_get_dgraph",
     "dddmr_rollout_marking_get_lethal",
+    "dddmr_rollout_marking_route_counts",
     "dddmr_rollout_stream_ceiling",
     "dddmr_rollout_selftest_sincos",
     "dddmr_rollout_last_error",
@@ -284,6 +288,12 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_comm_init.restype = C.c_int
     lib.dddmr_rollout_comm_destroy.argtypes = [ctx_p]
     lib.dddmr_rollout_comm_destroy.restype = C.c_int
+    lib.dddmr_rollout_comm_ranks.argtypes = [ctx_p, C.POINTER(C.c_int32)]
+    lib.dddmr_rollout_comm_ranks.restype = C.c_int
+    lib.dddmr_rollout_comm_loopback.argtypes = [ctx_p]
+    lib.dddmr_rollout_comm_loopback.restype = C.c_int
+    lib.dddmr_rollout_comm_loopback_set_peer.argtypes = [ctx_p, C.c_int32, C.POINTER(C.c_int64)]
+    lib.dddmr_rollout_comm_loopback_set_peer.restype = C.c_int
     lib.dddmr_rollout_marking_create.argtypes = [ctx_p, C.POINTER(MarkingConfig), C.c_void_p, C.c_size_t, C.c_size_t,
                                                  C.c_void_p, C.c_size_t, C.c_size_t]
     lib.dddmr_rollout_marking_create.restype = C.c_int
@@ -297,6 +307,8 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_marking_get_dgraph.restype = C.c_int
     lib.dddmr_rollout_marking_get_lethal.argtypes = [ctx_p, C.c_void_p, C.c_size_t]
     lib.dddmr_rollout_marking_get_lethal.restype = C.c_int
+    lib.dddmr_rollout_marking_route_counts.argtypes = [ctx_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.dddmr_rollout_marking_route_counts.restype = C.c_int
     lib.dddmr_rollout_stream_ceiling.argtypes = [ctx_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.dddmr_rollout_stream_ceiling.restype = C.c_int
     lib.dddmr_rollout_selftest_sincos.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -132,6 +132,7 @@ struct MarkCounters {         // device counters of one update (copied back for 
   uint32_t n_dup;   // clusters of this update that found their voxel already claimed by another one (marking_fix_ties)
   uint32_t n_new_keys;   // voxels that entered the store for the first time in this update (store garbage collection)
   uint32_t n_rehashed;   // alive markings moved by this update's garbage collection
+  uint32_t fallback;     // fused route: the voxel sort keys did not fit, the mark phase has to take the general route
 };
 
 // isinLidarObservation (:682-746).  The reference builds a rotation that turns the x axis onto the viewing
@@ -218,9 +219,11 @@ __global__ __launch_bounds__(256) void k_mk_fov(MarkParams k, MarkStore s, MarkC
   s.fov_flag[w] = flag;
 }
 
-__global__ __launch_bounds__(256) void k_mk_clear(MarkParams k, MarkStore s, PointGrid prev, MarkCounters* __restrict__ cnt) {
-  const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+// The ray test of one stored marking by one wave.  removed_on (the fused route, marking_fused.hip.h): the pool range of
+// a removed marking is recorded with it, because that route's commit may hand the slot to a new cluster in the same
+// launch that runs removePCPtr.
+__device__ __forceinline__ void mk_clear_wave(const MarkParams& k, const MarkStore& s, const PointGrid& prev, MarkCounters* __restrict__ cnt,
+                                              const uint32_t w, const int lane, uint2* __restrict__ removed_on) {
   if (w >= k.n_alive_prev || !s.fov_flag[w]) return;
   const uint32_t slot = s.alive_list[w];
   int x, y, z;
@@ -271,8 +274,13 @@ __global__ __launch_bounds__(256) void k_mk_clear(MarkParams k, MarkStore s, Poi
     s.alive[slot] = 0;
     s.removed_seq[slot] = k.seq;
     atomicAdd(&cnt->n_cleared, 1u);
-    s.removed_list[atomicAdd(&cnt->n_removed, 1u)] = slot;
+    const uint32_t at = atomicAdd(&cnt->n_removed, 1u);
+    s.removed_list[at] = slot;
+    if (removed_on) removed_on[at] = make_uint2(s.pts_ofs[slot], s.pts_n[slot]);
   }
+}
+__global__ __launch_bounds__(256) void k_mk_clear(MarkParams k, MarkStore s, PointGrid prev, MarkCounters* __restrict__ cnt) {
+  mk_clear_wave(k, s, prev, cnt, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, nullptr);
 }
 
 // removePCPtr's loop over nodes_of_min_distance_, recomputed from the marking's generator points: every ground node

@@ -6,10 +6,13 @@
 #include <unordered_map>
 
 #include "marking.hip.h"
+#include "marking_fused.hip.h"
 
 namespace {
 
 using namespace dddmr;
+
+constexpr uint32_t kMarkMaxObs = 1u << 20;   // points of one observation (20-bit point index inside the sort keys)
 
 struct GridBuf {              // a PointGrid with its storage
   PointGrid g;
@@ -44,6 +47,15 @@ struct MarkingState {
   size_t temp_bytes = 0;
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   uint32_t seq = 0;
+  // fused route (marking_fused.hip.h)
+  uint2* removed_on = nullptr;             // [table]
+  uint32_t* ticket = nullptr;              // [2]
+  MarkCounters* host_out = nullptr;        // host-mapped (hipHostMalloc), host_out_dev = its device address
+  MarkCounters* host_out_dev = nullptr;
+  bool counters_clean = false;             // device counters zeroed (pool fill kept) by the last fused update
+  int route = -1;                          // DDDMR_MARKING_ROUTE: -1 by size, 0 general (rocPRIM), 1 fused only
+  uint32_t updates_fused = 0, updates_general = 0, launches_last = 0;
+  float last_clear_ms = 0.f, last_mark_ms = 0.f;
 };
 
 void free_grid(GridBuf& b) {
@@ -71,9 +83,10 @@ void marking_free(MarkingState* m) {
                m->gslot, m->parent, m->keys_a, m->keys_b, m->keys1, m->vals_a, m->vals_b, m->flags, m->incl, m->cid_incl, m->ds,
                m->proj, m->gen, m->ds_first, m->pool_ofs, m->compact_sizes, m->compact_ofs, m->cl.start, m->cl.size, m->cl.centroid,
                m->cl.state, m->cl.ds_count, m->cl.gen_first, m->cl.gen_count, m->cl.slot, m->cl.vkey, m->counters, m->n_groups,
-               m->temp};
+               m->temp, m->removed_on, m->ticket};
   for (void* q : p)
     if (q) (void)hipFree(q);
+  if (m->host_out) (void)hipHostFree(m->host_out);
   free_grid(m->ground); free_grid(m->map); free_grid(m->obs[0]); free_grid(m->obs[1]);
   if (m->e0) (void)hipEventDestroy(m->e0);
   if (m->e1) (void)hipEventDestroy(m->e1);
@@ -252,6 +265,10 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
       !(cfg->inflation_radius > 0) || cfg->max_markings == 0 || cfg->max_cluster_points == 0)
     return fail(ctx, DDDMR_ERR_BAD_ARG, "marking_create: resolutions, tolerance, inflation radius and capacities must be positive");
   if (n_ground >= (1u << 30) || cfg->max_markings > (1u << 24)) return fail(ctx, DDDMR_ERR_CAPACITY, "marking_create: too large");
+  // the sort keys of an update carry the observation point index in 20 bits ((root << 20) | i, cluster id << 42)
+  if (ctx->cfg.max_points > kMarkMaxObs)
+    return fail(ctx, DDDMR_ERR_CAPACITY, "marking_create: the context's max_points %u exceeds the layer's %u-point observations",
+                ctx->cfg.max_points, kMarkMaxObs);
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
   if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "marking_create while a tick_begin is pending");
   HIPCHK(ctx, hipSetDevice(ctx->device));
@@ -270,13 +287,14 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     const size_t N = m->max_obs;
     // rocPRIM temporary storage: the largest request among the sorts and scans used below
     {
-      size_t a = 0, b = 0, c = 0;
+      size_t a = 0, b = 0, c = 0, d = 0;
       unsigned long long* k = nullptr;
       uint32_t* v = nullptr;
       HIPCHK(ctx, rocprim::radix_sort_keys(nullptr, a, k, k, N, 0, 40, ctx->stream));
       HIPCHK(ctx, rocprim::radix_sort_pairs(nullptr, b, k, k, v, v, N, 0, 62, ctx->stream));
       HIPCHK(ctx, rocprim::exclusive_scan(nullptr, c, v, v, 0u, (size_t)(1u << 22) + 1, rocprim::plus<uint32_t>(), ctx->stream));
-      m->temp_bytes = std::max({a, b, c, (size_t)4096}) + 256;
+      HIPCHK(ctx, rocprim::inclusive_scan(nullptr, d, v, v, std::max<size_t>(N, m->table), rocprim::plus<uint32_t>(), ctx->stream));
+      m->temp_bytes = std::max({a, b, c, d, (size_t)4096}) + 256;
       HIPCHK(ctx, hipMalloc(&m->temp, m->temp_bytes));
     }
     int rc = upload_static(ctx, m, m->ground, &m->ground_pts, ground_xyz, n_ground, ground_stride_bytes, 0.5f, 1e6f);
@@ -334,6 +352,19 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     HIPCHK(ctx, hipMalloc(&m->cl.vkey, 3 * N * sizeof(int)));
     HIPCHK(ctx, hipMalloc(&m->counters, sizeof(MarkCounters)));
     HIPCHK(ctx, hipMalloc(&m->n_groups, 2 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->removed_on, (size_t)table * sizeof(uint2)));
+    HIPCHK(ctx, hipMalloc(&m->ticket, 2 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(m->ticket, 0, 2 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(m->counters, 0, sizeof(MarkCounters)));
+    HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->host_out), sizeof(MarkCounters), hipHostMallocMapped));
+    HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&m->host_out_dev), m->host_out, 0));
+    if (const char* e = std::getenv("DDDMR_MARKING_ROUTE")) m->route = std::strcmp(e, "general") == 0 ? 0 : (std::strcmp(e, "fused") == 0 ? 1 : -1);
+    {
+      const void* fk[] = {reinterpret_cast<const void*>(k_mkf_unmark_groups<4>), reinterpret_cast<const void*>(k_mkf_unmark_groups<8>),
+                          reinterpret_cast<const void*>(k_mkf_unmark_groups<16>)};
+      const size_t fl[] = {fuse_groups_lds_bytes<4>(), fuse_groups_lds_bytes<8>(), fuse_groups_lds_bytes<16>()};
+      for (int i = 0; i < 3; ++i) HIPCHK(ctx, hipFuncSetAttribute(fk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl[i]));
+    }
     HIPCHK(ctx, hipEventCreate(&m->e0));
     HIPCHK(ctx, hipEventCreate(&m->e1));
     HIPCHK(ctx, hipEventCreate(&m->e2));
@@ -374,7 +405,237 @@ int marking_reset_locked(dddmr_rollout_ctx* ctx) {
   m->pool_used_host = 0;
   m->n_alive_host = 0;
   m->keys_used_host = 0;
+  m->counters_clean = false;
   // (pcl_msg_gbl_ is untouched by resetdGraph: the previous observation stays)
+  return DDDMR_OK;
+}
+
+struct UpdateFrame {          // host-side inputs of one update besides the kernel parameters
+  MarkParams k;
+  double Rb[9];               // rotation of T_gbl_base
+  double t_gb[3];
+};
+
+#define MK_LAUNCH(m, ...) do { hipLaunchKernelGGL(__VA_ARGS__); ++(m)->launches_last; } while (0)
+
+// Store garbage collection when half the table holds keys and a good part of them is dead; pool compaction when half
+// of the pool is garbage-or-used.  Both rare; both leave the device counters consistent for either route.
+int store_maintenance(dddmr_rollout_ctx* ctx, MarkingState* m, hipStream_t st) {
+  MarkStore& s = m->store;
+  if (m->keys_used_host > m->table / 2 && m->keys_used_host > m->n_alive_host + m->table / 8) {
+    const size_t t = m->table;
+    HIPCHK(ctx, hipMemsetAsync(m->keys_alt, 0, t * sizeof(unsigned long long), st));
+    HIPCHK(ctx, hipMemsetAsync(m->alive_alt, 0, t * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(m->pts_ofs_alt, 0, t * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(m->pts_n_alt, 0, t * sizeof(uint32_t), st));
+    MK_LAUNCH(m, k_mk_rehash, dim3((m->table + 255) / 256), dim3(256), 0, st, m->table - 1, s, m->keys_alt, m->alive_alt,
+              m->pts_ofs_alt, m->pts_n_alt, m->counters);
+    std::swap(s.keys, m->keys_alt);
+    std::swap(s.alive, m->alive_alt);
+    std::swap(s.pts_ofs, m->pts_ofs_alt);
+    std::swap(s.pts_n, m->pts_n_alt);
+    m->keys_used_host = m->n_alive_host;
+  }
+  if (m->pool_used_host > m->pool_cap / 2) {
+    MK_LAUNCH(m, k_mk_compact_sizes, dim3((m->table + 255) / 256), dim3(256), 0, st, m->table, s, m->compact_sizes);
+    size_t tb = m->temp_bytes;
+    HIPCHK(ctx, rocprim::exclusive_scan(m->temp, tb, m->compact_sizes, m->compact_ofs, 0u, (size_t)m->table, rocprim::plus<uint32_t>(), st));
+    HIPCHK(ctx, hipMemsetAsync(&m->counters->pool_used, 0, sizeof(uint32_t), st));
+    MK_LAUNCH(m, k_mk_compact_move, dim3((m->table + 3) / 4), dim3(256), 0, st, m->table, s, m->compact_ofs, m->pool_alt, m->counters);
+    std::swap(s.pool, m->pool_alt);
+  }
+  return DDDMR_OK;
+}
+
+// grid over the crop box of the feed (base frame |x|,|y| <= window, z in [0, marking_height]) in the global frame
+void obs_grid_shape(const MarkingState* m, const UpdateFrame& f, uint32_t cap_cells, PointGrid& g, float lo[3], float hi[3]) {
+  const dddmr_marking_config& c = m->cfg;
+  for (int a = 0; a < 3; ++a) { lo[a] = 3.4e38f; hi[a] = -3.4e38f; }
+  for (int corner = 0; corner < 8; ++corner) {
+    const double bx = (corner & 1) ? c.perception_window_size : -c.perception_window_size;
+    const double by = (corner & 2) ? c.perception_window_size : -c.perception_window_size;
+    const double bz = (corner & 4) ? c.marking_height : 0.0;
+    for (int a = 0; a < 3; ++a) {
+      const float v = (float)(f.Rb[3 * a] * bx + f.Rb[3 * a + 1] * by + f.Rb[3 * a + 2] * bz + f.t_gb[a]);
+      lo[a] = std::min(lo[a], v - 0.3f);
+      hi[a] = std::max(hi[a], v + 0.3f);
+    }
+  }
+  const float cell = std::max(0.1f, f.k.tol);
+  grid_shape(g, lo, hi, cell, cell, cap_cells);
+}
+
+// selfMark of this observation, general route: rocPRIM sorts, any observation size (marking.hip.h)
+int mark_general(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, const float4* obs, uint32_t n_obs, hipStream_t st) {
+  const MarkParams& k = f.k;
+  MarkStore& s = m->store;
+  const int cur = m->prev >= 0 ? 1 - m->prev : 0;
+  GridBuf& gb = m->obs[cur];
+  float lo[3], hi[3];
+  obs_grid_shape(m, f, gb.cap_cells, gb.g, lo, hi);
+  const float4* pts = obs;                   // (the cloud buffer stays pinned until the update returns)
+  int rc = grid_build(ctx, m, gb, pts, n_obs, m->gslot, st);
+  m->launches_last += 5;                     // memset, count, rocPRIM scan (2 kernels), scatter
+  if (rc != DDDMR_OK) return rc;
+  const dim3 pb((n_obs + 255) / 256), cb((n_obs + 63) / 64);
+  // Euclidean clusters
+  MK_LAUNCH(m, k_mk_cc_init, pb, dim3(256), 0, st, n_obs, m->parent);
+  MK_LAUNCH(m, k_mk_cc_union, pb, dim3(256), 0, st, k, gb.g, pts, m->parent);
+  MK_LAUNCH(m, k_mk_cc_keys, pb, dim3(256), 0, st, n_obs, m->parent, m->keys_a);
+  size_t tb = m->temp_bytes;
+  HIPCHK(ctx, rocprim::radix_sort_keys(m->temp, tb, m->keys_a, m->keys1, (size_t)n_obs, 0, 40, st));
+  MK_LAUNCH(m, k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys1, 20, m->flags);
+  tb = m->temp_bytes;
+  HIPCHK(ctx, rocprim::inclusive_scan(m->temp, tb, m->flags, m->cid_incl, (size_t)n_obs, rocprim::plus<uint32_t>(), st));
+  MK_LAUNCH(m, k_mk_cluster_starts, pb, dim3(256), 0, st, n_obs, m->flags, m->cid_incl, m->cl, m->counters);
+  MK_LAUNCH(m, k_mk_cluster_stage1, cb, dim3(64), 0, st, k, m->counters, m->cl, m->keys1, pts, m->ground.g);
+  // 0.2 m VoxelGrid of every surviving cluster: stable sort by (cluster, voxel), one lane per voxel
+  const int ox2 = (int)std::floor(lo[0] / 0.2f) - 16, oy2 = (int)std::floor(lo[1] / 0.2f) - 16, oz2 = (int)std::floor(lo[2] / 0.2f) - 16;
+  MK_LAUNCH(m, k_mk_ds_keys, pb, dim3(256), 0, st, k, m->keys1, m->cid_incl, m->cl, pts, ox2, oy2, oz2, m->keys_a, m->vals_a);
+  tb = m->temp_bytes;
+  HIPCHK(ctx, rocprim::radix_sort_pairs(m->temp, tb, m->keys_a, m->keys_b, m->vals_a, m->vals_b, (size_t)n_obs, 0, 62, st));
+  MK_LAUNCH(m, k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys_b, 0, m->flags);
+  tb = m->temp_bytes;
+  HIPCHK(ctx, rocprim::inclusive_scan(m->temp, tb, m->flags, m->incl, (size_t)n_obs, rocprim::plus<uint32_t>(), st));
+  HIPCHK(ctx, hipMemsetAsync(m->ds_first, 0xFF, (size_t)n_obs * sizeof(uint32_t), st));
+  MK_LAUNCH(m, k_mk_group_reduce, cb, dim3(64), 0, st, n_obs, m->keys_b, m->vals_b, m->flags, m->incl, 0, m->keys1, pts, m->ds,
+            m->cl.ds_count, m->ds_first, m->n_groups);
+  MK_LAUNCH(m, k_mk_cluster_stage2, cb, dim3(64), 0, st, k, m->counters, m->cl, m->map.g, m->n_map);
+  // projection on the base plane + 0.1 m VoxelGrid of the accepted clusters -> generator points
+  const int ox3 = (int)std::floor(lo[0] / 0.1f) - 64, oy3 = (int)std::floor(lo[1] / 0.1f) - 64, oz3 = (int)std::floor(lo[2] / 0.1f) - 64;
+  MK_LAUNCH(m, k_mk_proj_keys, pb, dim3(256), 0, st, k, m->n_groups, m->ds, m->cl, ox3, oy3, oz3, m->proj, m->keys_a, m->vals_a, n_obs);
+  tb = m->temp_bytes;
+  HIPCHK(ctx, rocprim::radix_sort_pairs(m->temp, tb, m->keys_a, m->keys_b, m->vals_a, m->vals_b, (size_t)n_obs, 0, 62, st));
+  MK_LAUNCH(m, k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys_b, 0, m->flags);
+  tb = m->temp_bytes;
+  HIPCHK(ctx, rocprim::inclusive_scan(m->temp, tb, m->flags, m->incl, (size_t)n_obs, rocprim::plus<uint32_t>(), st));
+  MK_LAUNCH(m, k_mk_group_reduce, cb, dim3(64), 0, st, n_obs, m->keys_b, m->vals_b, m->flags, m->incl, 1, m->keys1, m->proj, m->gen,
+            m->cl.gen_count, m->cl.gen_first, m->n_groups + 1);
+  m->launches_last += 3 * 10 + 2 * 3 + 1;   // rocPRIM: three sorts (block sort + ~8 merge passes + id wrapper), three scans, memset
+  // addPCPtr
+  MK_LAUNCH(m, k_mk_slots, cb, dim3(64), 0, st, k, m->counters, m->cl, s, m->counters);
+  MK_LAUNCH(m, k_mk_commit, cb, dim3(64), 0, st, k, m->counters, m->cl, s, m->counters, m->pool_ofs);
+  MK_LAUNCH(m, k_mk_dgraph, dim3((n_obs + 3) / 4), dim3(256), 0, st, k, m->n_groups + 1, m->gen, m->cl, m->pool_ofs, s, m->ground.g);
+  m->prev = cur;                                                               // pcl_msg_gbl_ of this selfMark
+  m->n_prev = n_obs;
+  return DDDMR_OK;
+}
+
+// one update on the general route (~55 launches for a 6 k-point observation)
+int update_general(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, const float4* obs, uint32_t n_obs, bool timed,
+                   MarkCounters& out) {
+  hipStream_t st = ctx->stream;
+  const MarkParams& k = f.k;
+  MarkStore& s = m->store;
+  MarkCounters zero{};
+  zero.pool_used = m->pool_used_host;
+  HIPCHK(ctx, hipMemcpyAsync(m->counters, &zero, sizeof(zero), hipMemcpyHostToDevice, st));   // (pageable source: copied before return)
+  m->counters_clean = false;
+  if (timed) HIPCHK(ctx, hipEventRecord(m->e0, st));
+  int rc = store_maintenance(ctx, m, st);
+  if (rc != DDDMR_OK) return rc;
+  // ---- selfClear against the previous observation ----
+  const PointGrid empty_grid = m->obs[0].g;
+  const PointGrid& prev_grid = m->prev >= 0 ? m->obs[m->prev].g : empty_grid;
+  if (m->n_alive_host > 0) {
+    MK_LAUNCH(m, k_mk_fov, dim3((m->n_alive_host + 255) / 256), dim3(256), 0, st, k, s, m->counters);
+    MK_LAUNCH(m, k_mk_clear, dim3((m->n_alive_host + 3) / 4), dim3(256), 0, st, k, s, prev_grid, m->counters);
+    MK_LAUNCH(m, k_mk_unmark, dim3((m->n_alive_host + 3) / 4), dim3(256), 0, st, k, s, m->ground.g, m->counters);
+  }
+  if (timed) HIPCHK(ctx, hipEventRecord(m->e1, st));
+  if (n_obs > 5) {                                                               // :320-321
+    rc = mark_general(ctx, m, f, obs, n_obs, st);
+    if (rc != DDDMR_OK) return rc;
+  }
+  MK_LAUNCH(m, k_mk_finish, dim3((m->table + 255) / 256), dim3(256), 0, st, k, s, m->counters);
+  if (timed) HIPCHK(ctx, hipEventRecord(m->e2, st));
+  HIPCHK(ctx, hipMemcpyAsync(&out, m->counters, sizeof(out), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  HIPCHK(ctx, hipGetLastError());
+  ++m->updates_general;
+  return DDDMR_OK;
+}
+
+// one update on the fused route: four launches, no copies (marking_fused.hip.h)
+int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, const float4* obs, uint32_t n_obs, bool timed,
+                 MarkCounters& out) {
+  hipStream_t st = ctx->stream;
+  const MarkParams& k = f.k;
+  MarkStore& s = m->store;
+  if (!m->counters_clean) {
+    MarkCounters zero{};
+    zero.pool_used = m->pool_used_host;
+    HIPCHK(ctx, hipMemcpyAsync(m->counters, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(m->ticket, 0, 2 * sizeof(uint32_t), st));
+  }
+  m->counters_clean = false;                 // (until this update's last block has run)
+  if (timed) HIPCHK(ctx, hipEventRecord(m->e0, st));
+  int rc = store_maintenance(ctx, m, st);
+  if (rc != DDDMR_OK) return rc;
+  const bool mark = n_obs > 5;                                                   // :320-321
+  const int cur = m->prev >= 0 ? 1 - m->prev : 0;
+  GridBuf& gb = m->obs[cur];
+  const PointGrid empty_grid = m->obs[0].g;
+  const PointGrid prev_grid = m->prev >= 0 ? m->obs[m->prev].g : empty_grid;
+  if (mark) {
+    float lo[3], hi[3];
+    obs_grid_shape(m, f, std::min(gb.cap_cells, kFuseMaxCells), gb.g, lo, hi);
+    gb.g.n = n_obs;
+  }
+  FuseBufs fb{obs, m->parent, m->proj, m->ds, m->gen, m->pool_ofs, m->removed_on, m->ticket, m->host_out_dev};
+  const uint32_t n_alive = m->n_alive_host;
+  // 1: observation grid | window + FOV test
+  if (mark || n_alive)
+    MK_LAUNCH(m, k_mkf_pre, dim3(1 + (n_alive + kFuseThreads - 1) / kFuseThreads), dim3(kFuseThreads), 0, st, k, s, gb.g, obs, m->parent,
+              m->counters);
+  // 2: ray tests | union-find
+  const uint32_t nb_clear = (n_alive + 3) / 4, nb_cc = mark ? (n_obs * 4 + 255) / 256 : 0;
+  if (nb_clear + nb_cc)
+    MK_LAUNCH(m, k_mkf_clear_cc, dim3(nb_clear + nb_cc), dim3(256), 0, st, k, s, prev_grid, gb.g, obs, m->parent, m->removed_on, m->counters,
+              nb_clear);
+  if (timed) HIPCHK(ctx, hipEventRecord(m->e1, st));
+  // 3: the grouping chain in one workgroup | removePCPtr of the cleared markings
+  const uint32_t nb_un = n_alive ? std::min<uint32_t>(255u, (n_alive + 63) / 64) : 0;
+  if (mark || nb_un) {
+    const dim3 g3(1 + nb_un), b3(kFuseThreads);
+    if (n_obs <= 4096)
+      MK_LAUNCH(m, k_mkf_unmark_groups<4>, g3, b3, fuse_groups_lds_bytes<4>(), st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map, m->counters);
+    else if (n_obs <= 8192)
+      MK_LAUNCH(m, k_mkf_unmark_groups<8>, g3, b3, fuse_groups_lds_bytes<8>(), st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map, m->counters);
+    else
+      MK_LAUNCH(m, k_mkf_unmark_groups<16>, g3, b3, fuse_groups_lds_bytes<16>(), st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map, m->counters);
+  }
+  // 4: dGraph of the new generator points | alive list; the last block publishes the counters
+  const uint32_t nb_dg = mark ? std::min<uint32_t>((n_obs + 3) / 4, 2048u) : 0, nb_fin = (m->table + 255) / 256;
+  MK_LAUNCH(m, k_mkf_dgraph_finish, dim3(nb_dg + nb_fin), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters, nb_dg);
+  if (timed) HIPCHK(ctx, hipEventRecord(m->e2, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  HIPCHK(ctx, hipGetLastError());
+  out = *m->host_out;
+  m->counters_clean = true;
+  ++m->updates_fused;
+  if (mark && !out.fallback) {
+    m->prev = cur;                                                               // pcl_msg_gbl_ of this selfMark
+    m->n_prev = n_obs;
+  }
+  if (!out.fallback) return DDDMR_OK;
+  // The observation's voxel range did not fit the 28-bit sort keys (points hundreds of metres apart: only a cloud
+  // handed over with set_cloud can do that): the clear phase stands, the mark phase is redone on the general route.
+  --m->updates_fused;
+  m->counters_clean = false;
+  rc = mark_general(ctx, m, f, obs, n_obs, st);
+  if (rc != DDDMR_OK) return rc;
+  HIPCHK(ctx, hipMemsetAsync(&m->counters->n_alive, 0, sizeof(uint32_t), st));
+  MK_LAUNCH(m, k_mk_finish, dim3((m->table + 255) / 256), dim3(256), 0, st, k, s, m->counters);
+  if (timed) HIPCHK(ctx, hipEventRecord(m->e2, st));
+  MarkCounters g{};
+  HIPCHK(ctx, hipMemcpyAsync(&g, m->counters, sizeof(g), hipMemcpyDeviceToHost, st));
+  HIPCHK(ctx, hipStreamSynchronize(st));
+  HIPCHK(ctx, hipGetLastError());
+  g.n_in_window = out.n_in_window; g.n_cleared = out.n_cleared; g.n_removed = out.n_removed; g.n_rehashed = out.n_rehashed;
+  g.fallback = 1u;
+  out = g;
+  ++m->updates_general;
   return DDDMR_OK;
 }
 }  // namespace
@@ -401,15 +662,18 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
   }
   const uint32_t n_obs = ctx->cloud_n[cidx];
   const float4* obs = ctx->cloud_dev[cidx];
+  if (n_obs > m->max_obs) return fail(ctx, DDDMR_ERR_CAPACITY, "marking_update: observation of %u points, layer sized for %u", n_obs, m->max_obs);
 
   // ---- transforms (host, double): trans_gbl2s_af3_ = gbl2b * b2s (:236-237), its tf2 form (:238) ----
-  MarkParams k{};
-  double Rb[9], Rbs[9], Rs_e[9], ts[3];
-  quat_to_rot(T_gbl_base, Rb);
+  UpdateFrame f{};
+  MarkParams& k = f.k;
+  double Rbs[9], Rs_e[9], ts[3];
+  quat_to_rot(T_gbl_base, f.Rb);
   quat_to_rot(T_base_sensor, Rbs);
   for (int i = 0; i < 3; ++i) {
-    for (int j = 0; j < 3; ++j) Rs_e[3 * i + j] = Rb[3 * i + 0] * Rbs[0 + j] + Rb[3 * i + 1] * Rbs[3 + j] + Rb[3 * i + 2] * Rbs[6 + j];
-    ts[i] = Rb[3 * i + 0] * T_base_sensor[0] + Rb[3 * i + 1] * T_base_sensor[1] + Rb[3 * i + 2] * T_base_sensor[2] + T_gbl_base[i];
+    for (int j = 0; j < 3; ++j) Rs_e[3 * i + j] = f.Rb[3 * i + 0] * Rbs[0 + j] + f.Rb[3 * i + 1] * Rbs[3 + j] + f.Rb[3 * i + 2] * Rbs[6 + j];
+    ts[i] = f.Rb[3 * i + 0] * T_base_sensor[0] + f.Rb[3 * i + 1] * T_base_sensor[1] + f.Rb[3 * i + 2] * T_base_sensor[2] + T_gbl_base[i];
+    f.t_gb[i] = T_gbl_base[i];
   }
   double qs[4];
   rot_to_quat(Rs_e, qs);
@@ -448,124 +712,25 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
   k.seq = ++m->seq;
   if (k.seq == 0) k.seq = m->seq = 1;
 
-  MarkStore& s = m->store;
-  MarkCounters zero{};
-  zero.pool_used = m->pool_used_host;
-  HIPCHK(ctx, hipMemcpyAsync(m->counters, &zero, sizeof(zero), hipMemcpyHostToDevice, st));   // (pageable source: copied before return)
-  HIPCHK(ctx, hipEventRecord(m->e0, st));
-
-  // ---- store garbage collection when half the table holds keys and a good part of them is dead ----
-  if (m->keys_used_host > m->table / 2 && m->keys_used_host > m->n_alive_host + m->table / 8) {
-    const size_t t = m->table;
-    HIPCHK(ctx, hipMemsetAsync(m->keys_alt, 0, t * sizeof(unsigned long long), st));
-    HIPCHK(ctx, hipMemsetAsync(m->alive_alt, 0, t * sizeof(uint32_t), st));
-    HIPCHK(ctx, hipMemsetAsync(m->pts_ofs_alt, 0, t * sizeof(uint32_t), st));
-    HIPCHK(ctx, hipMemsetAsync(m->pts_n_alt, 0, t * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_mk_rehash, dim3((m->table + 255) / 256), dim3(256), 0, st, m->table - 1, s, m->keys_alt, m->alive_alt,
-                       m->pts_ofs_alt, m->pts_n_alt, m->counters);
-    std::swap(s.keys, m->keys_alt);
-    std::swap(s.alive, m->alive_alt);
-    std::swap(s.pts_ofs, m->pts_ofs_alt);
-    std::swap(s.pts_n, m->pts_n_alt);
-    m->keys_used_host = m->n_alive_host;
-  }
-
-  // ---- pool compaction when half of it is garbage-or-used ----
-  if (m->pool_used_host > m->pool_cap / 2) {
-    hipLaunchKernelGGL(k_mk_compact_sizes, dim3((m->table + 255) / 256), dim3(256), 0, st, m->table, s, m->compact_sizes);
-    size_t tb = m->temp_bytes;
-    HIPCHK(ctx, rocprim::exclusive_scan(m->temp, tb, m->compact_sizes, m->compact_ofs, 0u, (size_t)m->table, rocprim::plus<uint32_t>(), st));
-    HIPCHK(ctx, hipMemsetAsync(&m->counters->pool_used, 0, sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_mk_compact_move, dim3((m->table + 3) / 4), dim3(256), 0, st, m->table, s, m->compact_ofs, m->pool_alt, m->counters);
-    std::swap(s.pool, m->pool_alt);
-  }
-
-  // ---- selfClear against the previous observation ----
-  const PointGrid empty_grid = m->obs[0].g;
-  const PointGrid& prev_grid = m->prev >= 0 ? m->obs[m->prev].g : empty_grid;
-  if (m->n_alive_host > 0) {
-    hipLaunchKernelGGL(k_mk_fov, dim3((m->n_alive_host + 255) / 256), dim3(256), 0, st, k, s, m->counters);
-    hipLaunchKernelGGL(k_mk_clear, dim3((m->n_alive_host + 3) / 4), dim3(256), 0, st, k, s, prev_grid, m->counters);
-    hipLaunchKernelGGL(k_mk_unmark, dim3((m->n_alive_host + 3) / 4), dim3(256), 0, st, k, s, m->ground.g, m->counters);
-  }
-  HIPCHK(ctx, hipEventRecord(m->e1, st));
-
-  // ---- selfMark of this observation ----
-  if (n_obs > 5) {                                                               // :320-321
-    const int cur = m->prev >= 0 ? 1 - m->prev : 0;
-    GridBuf& gb = m->obs[cur];
-    // grid over the crop box of the feed (base frame |x|,|y| <= window, z in [0, marking_height]) in the global frame
-    float lo[3], hi[3];
-    for (int a = 0; a < 3; ++a) { lo[a] = 3.4e38f; hi[a] = -3.4e38f; }
-    for (int corner = 0; corner < 8; ++corner) {
-      const double bx = (corner & 1) ? c.perception_window_size : -c.perception_window_size;
-      const double by = (corner & 2) ? c.perception_window_size : -c.perception_window_size;
-      const double bz = (corner & 4) ? c.marking_height : 0.0;
-      for (int a = 0; a < 3; ++a) {
-        const float v = (float)(Rb[3 * a] * bx + Rb[3 * a + 1] * by + Rb[3 * a + 2] * bz + T_gbl_base[a]);
-        lo[a] = std::min(lo[a], v - 0.3f);
-        hi[a] = std::max(hi[a], v + 0.3f);
-      }
-    }
-    const float cell = std::max(0.1f, k.tol);
-    grid_shape(gb.g, lo, hi, cell, cell, gb.cap_cells);
-    HIPCHK(ctx, hipMemcpyAsync(m->obs_copy[cur], obs, (size_t)n_obs * sizeof(float4), hipMemcpyDeviceToDevice, st));
-    const float4* pts = m->obs_copy[cur];
-    int rc = grid_build(ctx, m, gb, pts, n_obs, m->gslot, st);
-    if (rc != DDDMR_OK) return rc;
-    const dim3 pb((n_obs + 255) / 256), cb((n_obs + 63) / 64);
-    // Euclidean clusters
-    hipLaunchKernelGGL(k_mk_cc_init, pb, dim3(256), 0, st, n_obs, m->parent);
-    hipLaunchKernelGGL(k_mk_cc_union, pb, dim3(256), 0, st, k, gb.g, pts, m->parent);
-    hipLaunchKernelGGL(k_mk_cc_keys, pb, dim3(256), 0, st, n_obs, m->parent, m->keys_a);
-    size_t tb = m->temp_bytes;
-    HIPCHK(ctx, rocprim::radix_sort_keys(m->temp, tb, m->keys_a, m->keys1, (size_t)n_obs, 0, 40, st));
-    hipLaunchKernelGGL(k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys1, 20, m->flags);
-    tb = m->temp_bytes;
-    HIPCHK(ctx, rocprim::inclusive_scan(m->temp, tb, m->flags, m->cid_incl, (size_t)n_obs, rocprim::plus<uint32_t>(), st));
-    hipLaunchKernelGGL(k_mk_cluster_starts, pb, dim3(256), 0, st, n_obs, m->flags, m->cid_incl, m->cl, m->counters);
-    hipLaunchKernelGGL(k_mk_cluster_stage1, cb, dim3(64), 0, st, k, m->counters, m->cl, m->keys1, pts, m->ground.g);
-    // 0.2 m VoxelGrid of every surviving cluster: stable sort by (cluster, voxel), one lane per voxel
-    const int ox2 = (int)std::floor(lo[0] / 0.2f) - 16, oy2 = (int)std::floor(lo[1] / 0.2f) - 16, oz2 = (int)std::floor(lo[2] / 0.2f) - 16;
-    hipLaunchKernelGGL(k_mk_ds_keys, pb, dim3(256), 0, st, k, m->keys1, m->cid_incl, m->cl, pts, ox2, oy2, oz2, m->keys_a, m->vals_a);
-    tb = m->temp_bytes;
-    HIPCHK(ctx, rocprim::radix_sort_pairs(m->temp, tb, m->keys_a, m->keys_b, m->vals_a, m->vals_b, (size_t)n_obs, 0, 62, st));
-    hipLaunchKernelGGL(k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys_b, 0, m->flags);
-    tb = m->temp_bytes;
-    HIPCHK(ctx, rocprim::inclusive_scan(m->temp, tb, m->flags, m->incl, (size_t)n_obs, rocprim::plus<uint32_t>(), st));
-    HIPCHK(ctx, hipMemsetAsync(m->ds_first, 0xFF, (size_t)n_obs * sizeof(uint32_t), st));
-    hipLaunchKernelGGL(k_mk_group_reduce, cb, dim3(64), 0, st, n_obs, m->keys_b, m->vals_b, m->flags, m->incl, 0, m->keys1, pts, m->ds,
-                       m->cl.ds_count, m->ds_first, m->n_groups);
-    hipLaunchKernelGGL(k_mk_cluster_stage2, cb, dim3(64), 0, st, k, m->counters, m->cl, m->map.g, m->n_map);
-    // projection on the base plane + 0.1 m VoxelGrid of the accepted clusters -> generator points
-    const int ox3 = (int)std::floor(lo[0] / 0.1f) - 64, oy3 = (int)std::floor(lo[1] / 0.1f) - 64, oz3 = (int)std::floor(lo[2] / 0.1f) - 64;
-    hipLaunchKernelGGL(k_mk_proj_keys, pb, dim3(256), 0, st, k, m->n_groups, m->ds, m->cl, ox3, oy3, oz3, m->proj, m->keys_a, m->vals_a, n_obs);
-    tb = m->temp_bytes;
-    HIPCHK(ctx, rocprim::radix_sort_pairs(m->temp, tb, m->keys_a, m->keys_b, m->vals_a, m->vals_b, (size_t)n_obs, 0, 62, st));
-    hipLaunchKernelGGL(k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys_b, 0, m->flags);
-    tb = m->temp_bytes;
-    HIPCHK(ctx, rocprim::inclusive_scan(m->temp, tb, m->flags, m->incl, (size_t)n_obs, rocprim::plus<uint32_t>(), st));
-    hipLaunchKernelGGL(k_mk_group_reduce, cb, dim3(64), 0, st, n_obs, m->keys_b, m->vals_b, m->flags, m->incl, 1, m->keys1, m->proj, m->gen,
-                       m->cl.gen_count, m->cl.gen_first, m->n_groups + 1);
-    // addPCPtr
-    hipLaunchKernelGGL(k_mk_slots, cb, dim3(64), 0, st, k, m->counters, m->cl, s, m->counters);
-    hipLaunchKernelGGL(k_mk_commit, cb, dim3(64), 0, st, k, m->counters, m->cl, s, m->counters, m->pool_ofs);
-    hipLaunchKernelGGL(k_mk_dgraph, dim3((n_obs + 3) / 4), dim3(256), 0, st, k, m->n_groups + 1, m->gen, m->cl, m->pool_ofs, s, m->ground.g);
-    m->prev = cur;                                                               // pcl_msg_gbl_ of this selfMark
-    m->n_prev = n_obs;
-  }
-  hipLaunchKernelGGL(k_mk_finish, dim3((m->table + 255) / 256), dim3(256), 0, st, k, s, m->counters);
-  HIPCHK(ctx, hipEventRecord(m->e2, st));
+  // HIP events serialise the queue around them: the update is timed like the tick (DDDMR_TIMING / _EVERY)
+  const bool timed = stats && ctx->timing >= 1 && (m->seq % (uint32_t)ctx->timing_every) == 0;
   MarkCounters out{};
-  HIPCHK(ctx, hipMemcpyAsync(&out, m->counters, sizeof(out), hipMemcpyDeviceToHost, st));
-  HIPCHK(ctx, hipStreamSynchronize(st));
-  HIPCHK(ctx, hipGetLastError());
+  m->launches_last = 0;
+  const bool fused = m->route != 0 && n_obs <= kFuseMaxObs;
+  if (m->route == 1 && !fused)
+    return fail(ctx, DDDMR_ERR_CAPACITY, "marking_update: DDDMR_MARKING_ROUTE=fused, observation of %u points > %u", n_obs, kFuseMaxObs);
+  const int rc = fused ? update_fused(ctx, m, f, obs, n_obs, timed, out) : update_general(ctx, m, f, obs, n_obs, timed, out);
+  if (rc != DDDMR_OK) return rc;
   m->pool_used_host = out.pool_used;
   m->n_alive_host = out.n_alive;
   m->keys_used_host += out.n_new_keys;
   if (out.n_dup > 0 && !out.overflow) {
-    const int rc = marking_fix_ties(ctx, m, k, s, out);
-    if (rc != DDDMR_OK) return rc;
+    const int rt = marking_fix_ties(ctx, m, k, m->store, out);
+    if (rt != DDDMR_OK) return rt;
+  }
+  if (timed) {
+    HIPCHK(ctx, hipEventElapsedTime(&m->last_clear_ms, m->e0, m->e1));
+    HIPCHK(ctx, hipEventElapsedTime(&m->last_mark_ms, m->e1, m->e2));
   }
   if (stats) {
     stats->n_observation = n_obs > 5 ? n_obs : 0;
@@ -574,11 +739,23 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
     stats->n_in_window = out.n_in_window;
     stats->n_cleared = out.n_cleared;
     stats->n_alive = out.n_alive;
-    HIPCHK(ctx, hipEventElapsedTime(&stats->clear_ms, m->e0, m->e1));
-    HIPCHK(ctx, hipEventElapsedTime(&stats->mark_ms, m->e1, m->e2));
+    stats->clear_ms = m->last_clear_ms;       // the latest timed update's
+    stats->mark_ms = m->last_mark_ms;
   }
   if (out.overflow)
     return fail(ctx, DDDMR_ERR_CAPACITY, "marking_update: capacity flag %u (1: max_markings, 2: max_cluster_points)", out.overflow);
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_marking_route_counts(dddmr_rollout_ctx* ctx, uint32_t* updates_fused, uint32_t* updates_general,
+                                       uint32_t* launches_last_update) {
+  if (!ctx) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  MarkingState* m = ctx->marking;
+  if (!m) return fail(ctx, DDDMR_ERR_STATE, "marking_route_counts before marking_create");
+  if (updates_fused) *updates_fused = m->updates_fused;
+  if (updates_general) *updates_general = m->updates_general;
+  if (launches_last_update) *launches_last_update = m->launches_last;
   return DDDMR_OK;
 }
 

@@ -231,6 +231,7 @@ struct dddmr_rollout_ctx {
   // runs k_score -> ncclAllReduce(min) of the ranks' (cost bits, -index) slots -> k_resolve on `stream`
   ncclComm_t comm = nullptr;
   int comm_ranks = 0;
+  bool comm_loopback = false;        // single-device rehearsal of the exchange: the peers' words are set by the host
   int64_t* slots_dev = nullptr;      // [2 * comm_ranks] send: own slot written by k_score, INT64_MAX elsewhere
   int64_t* slots_red = nullptr;      // [2 * comm_ranks] receive
   DevResult* local_result_dev = nullptr;
@@ -281,6 +282,7 @@ struct Rccl {
   ncclResult_t (*get_unique_id)(ncclUniqueId*) = nullptr;
   ncclResult_t (*comm_init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*comm_destroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*comm_count)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*all_reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*error_string)(ncclResult_t) = nullptr;
   std::string why;
@@ -301,9 +303,10 @@ Rccl& rccl() {
     r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(h, "ncclGetUniqueId"));
     r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(h, "ncclCommInitRank"));
     r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    r.comm_count = reinterpret_cast<decltype(r.comm_count)>(dlsym(h, "ncclCommCount"));
     r.all_reduce = reinterpret_cast<decltype(r.all_reduce)>(dlsym(h, "ncclAllReduce"));
     r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(h, "ncclGetErrorString"));
-    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_reduce || !r.error_string) {
+    if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.comm_count || !r.all_reduce || !r.error_string) {
       r.why = "librccl lacks an expected symbol";
       return;
     }
@@ -1098,8 +1101,10 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   const bool one_round = k.n_local <= 0 || (k.n_local + tile - 1) / tile <= ctx->n_cu * (thr == 512 ? 2 : 4);
   k.final_kernel = ctx->final_mode >= 0 ? ctx->final_mode : (one_round ? 0 : 1);
 
-  if (k.n_local > 0) {
-    // small per-tick uploads (sample axes or explicit list)
+  // small per-tick uploads (sample axes or explicit list).  A rank with an EMPTY shard needs them too when the context
+  // has a communicator: k_resolve decodes the global winner's command from them on every rank (rotate-in-place has two
+  // samples, so rank 0 of three or more ranks owns none).
+  if (k.n_local > 0 || ctx->comm || ctx->comm_loopback) {
     if (w.list_mode) {
       std::memcpy(ctx->small_stage, w.list.data(), N * sizeof(float4));
       HIPCHK(ctx, hipMemcpyAsync(ctx->samples_dev, ctx->small_stage, N * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
@@ -1117,6 +1122,8 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
       std::memcpy(a + k.ath_ofs, w.ath.data(), w.ath.size() * sizeof(float));
       HIPCHK(ctx, hipMemcpyAsync(ctx->axes_dev, a, 3 * kMaxAxis * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     }
+  }
+  if (k.n_local > 0) {
     // state arrays of the body-frame rollout
     const size_t need = (size_t)k.n_local * (size_t)s_tick;
     if (need > ctx->st_cap || !ctx->traj_info) {
@@ -1208,8 +1215,9 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   if (timed) HIPCHK(ctx, hipEventRecord(ctx->evs0, ctx->stream));
   // multi-rank context: k_score leaves the shard's winner on the device (staging record + its slot of
   // the all-reduce), k_resolve publishes the global one
-  DevResult* score_result = ctx->comm ? ctx->local_result_dev : ctx->result_dev;
-  int64_t* score_words = ctx->comm ? ctx->slots_dev + 2 * rank : nullptr;
+  const bool exchange = ctx->comm || ctx->comm_loopback;
+  DevResult* score_result = exchange ? ctx->local_result_dev : ctx->result_dev;
+  int64_t* score_words = exchange ? ctx->slots_dev + 2 * rank : nullptr;
   if (k.n_local > 0) {
     const int wgs = k.n_tiles;
     const bool lean = !k.want_minmax && !k.rec_pose && k.box_fast;
@@ -1231,10 +1239,17 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   if (k.n_local > 0 && k.final_kernel)
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(64), 0, ctx->stream, k, ctx->best_key, ctx->costs, ctx->samples_out,
                        ctx->cell_start, ctx->overflow, score_result, score_words);
-  if (ctx->comm) {
-    const int nrc = rccl().all_reduce(ctx->slots_dev, ctx->slots_red, (size_t)2 * ctx->comm_ranks, ncclInt64, ncclMin,
-                                      ctx->comm, ctx->stream);
-    if (nrc != ncclSuccess) return fail(ctx, DDDMR_ERR_HIP, "ncclAllReduce failed: %s", rccl().error_string((ncclResult_t)nrc));
+  if (exchange) {
+    // ONE collective per tick, on the tick's stream: ordered after k_score / k_finalize (which wrote this rank's two
+    // words of slots_dev) and before k_resolve by stream order alone; no host synchronisation in between.
+    if (ctx->comm) {
+      const int nrc = rccl().all_reduce(ctx->slots_dev, ctx->slots_red, (size_t)2 * ctx->comm_ranks, ncclInt64, ncclMin,
+                                        ctx->comm, ctx->stream);
+      if (nrc != ncclSuccess) return fail(ctx, DDDMR_ERR_HIP, "ncclAllReduce failed: %s", rccl().error_string((ncclResult_t)nrc));
+    } else {
+      HIPCHK(ctx, hipMemcpyAsync(ctx->slots_red, ctx->slots_dev, (size_t)2 * ctx->comm_ranks * sizeof(int64_t),
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    }
     hipLaunchKernelGGL(k_resolve, dim3(1), dim3(64), 0, ctx->stream, k, ctx->slots_red, ctx->comm_ranks,
                        ctx->local_result_dev, ctx->axes_dev, ctx->samples_dev, ctx->result_dev);
   }
@@ -1435,6 +1450,22 @@ int dddmr_rollout_comm_unique_id(uint8_t id_out[DDDMR_COMM_ID_BYTES]) {
   return DDDMR_OK;
 }
 
+// slot vectors of the per-tick exchange: [2 * n_ranks] words to send (own pair written by k_score / k_finalize,
+// INT64_MAX elsewhere: the other ranks' slots never change) and to receive
+static int alloc_exchange_buffers(dddmr_rollout_ctx* ctx, int n_ranks) {
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  if (ctx->slots_dev) { (void)hipFree(ctx->slots_dev); ctx->slots_dev = nullptr; }      // (re-initialisation after comm_destroy)
+  if (ctx->slots_red) { (void)hipFree(ctx->slots_red); ctx->slots_red = nullptr; }
+  if (ctx->local_result_dev) { (void)hipFree(ctx->local_result_dev); ctx->local_result_dev = nullptr; }
+  HIPCHK(ctx, hipMalloc(&ctx->slots_dev, (size_t)2 * n_ranks * sizeof(int64_t)));
+  HIPCHK(ctx, hipMalloc(&ctx->slots_red, (size_t)2 * n_ranks * sizeof(int64_t)));
+  HIPCHK(ctx, hipMalloc(&ctx->local_result_dev, sizeof(DevResult)));
+  std::vector<int64_t> none((size_t)2 * n_ranks, INT64_MAX);
+  HIPCHK(ctx, hipMemcpy(ctx->slots_dev, none.data(), none.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  HIPCHK(ctx, hipMemcpy(ctx->slots_red, none.data(), none.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  return DDDMR_OK;
+}
+
 int dddmr_rollout_comm_init(dddmr_rollout_ctx* ctx, const uint8_t id[DDDMR_COMM_ID_BYTES], int32_t rank, int32_t n_ranks) {
   if (!ctx || !id) return DDDMR_ERR_BAD_ARG;
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
@@ -1444,17 +1475,10 @@ int dddmr_rollout_comm_init(dddmr_rollout_ctx* ctx, const uint8_t id[DDDMR_COMM_
   if (n_ranks != world || rank != std::min(std::max(0, ctx->cfg.rank), world - 1))
     return fail(ctx, DDDMR_ERR_BAD_ARG, "comm_init: rank %d of %d does not match the context's shard (rank %d of %d)", rank,
                 n_ranks, ctx->cfg.rank, world);
+  if (ctx->comm_loopback) return fail(ctx, DDDMR_ERR_STATE, "comm_init: the context is in loopback mode");
   if (!rccl().ok()) return fail(ctx, DDDMR_ERR_NO_DEVICE, "comm_init: %s", rccl().why.c_str());
-  HIPCHK(ctx, hipSetDevice(ctx->device));
-  if (ctx->slots_dev) { (void)hipFree(ctx->slots_dev); ctx->slots_dev = nullptr; }      // (re-initialisation after comm_destroy)
-  if (ctx->slots_red) { (void)hipFree(ctx->slots_red); ctx->slots_red = nullptr; }
-  if (ctx->local_result_dev) { (void)hipFree(ctx->local_result_dev); ctx->local_result_dev = nullptr; }
-  HIPCHK(ctx, hipMalloc(&ctx->slots_dev, (size_t)2 * n_ranks * sizeof(int64_t)));
-  HIPCHK(ctx, hipMalloc(&ctx->slots_red, (size_t)2 * n_ranks * sizeof(int64_t)));
-  HIPCHK(ctx, hipMalloc(&ctx->local_result_dev, sizeof(DevResult)));
-  std::vector<int64_t> none((size_t)2 * n_ranks, INT64_MAX);     // the other ranks' slots never change
-  HIPCHK(ctx, hipMemcpy(ctx->slots_dev, none.data(), none.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-  HIPCHK(ctx, hipMemcpy(ctx->slots_red, none.data(), none.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  const int ab = alloc_exchange_buffers(ctx, n_ranks);
+  if (ab != DDDMR_OK) return ab;
   ncclUniqueId uid;
   std::memcpy(uid.internal, id, DDDMR_COMM_ID_BYTES);
   ncclComm_t comm = nullptr;
@@ -1469,12 +1493,53 @@ int dddmr_rollout_comm_destroy(dddmr_rollout_ctx* ctx) {
   if (!ctx) return DDDMR_ERR_BAD_ARG;
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
   if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "comm_destroy while a tick_begin is pending");
-  if (!ctx->comm) return DDDMR_OK;
+  if (!ctx->comm && !ctx->comm_loopback) return DDDMR_OK;
   HIPCHK(ctx, hipSetDevice(ctx->device));
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-  (void)rccl().comm_destroy(ctx->comm);
+  if (ctx->comm) (void)rccl().comm_destroy(ctx->comm);
   ctx->comm = nullptr;
+  ctx->comm_loopback = false;
   ctx->comm_ranks = 0;
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_comm_ranks(dddmr_rollout_ctx* ctx, int32_t* n_ranks_out) {
+  if (!ctx || !n_ranks_out) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  *n_ranks_out = 0;
+  if (ctx->comm_loopback) { *n_ranks_out = ctx->comm_ranks; return DDDMR_OK; }
+  if (!ctx->comm) return DDDMR_OK;
+  int n = 0;
+  const ncclResult_t rc = rccl().comm_count(ctx->comm, &n);      // what RCCL itself says, not what we asked for
+  if (rc != ncclSuccess) return fail(ctx, DDDMR_ERR_HIP, "ncclCommCount failed: %s", rccl().error_string(rc));
+  *n_ranks_out = n;
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_comm_loopback(dddmr_rollout_ctx* ctx) {
+  if (!ctx) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "comm_loopback while a tick_begin is pending");
+  if (ctx->comm || ctx->comm_loopback) return fail(ctx, DDDMR_ERR_STATE, "comm_loopback: the context already has an exchange");
+  const int world = std::max(1, ctx->cfg.world_size);
+  const int ab = alloc_exchange_buffers(ctx, world);
+  if (ab != DDDMR_OK) return ab;
+  ctx->comm_loopback = true;
+  ctx->comm_ranks = world;
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_comm_loopback_set_peer(dddmr_rollout_ctx* ctx, int32_t peer_rank, const int64_t words[2]) {
+  if (!ctx || !words) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  if (!ctx->comm_loopback) return fail(ctx, DDDMR_ERR_STATE, "comm_loopback_set_peer: the context is not in loopback mode");
+  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "comm_loopback_set_peer while a tick_begin is pending");
+  const int world = ctx->comm_ranks, rank = std::min(std::max(0, ctx->cfg.rank), world - 1);
+  if (peer_rank < 0 || peer_rank >= world || peer_rank == rank)
+    return fail(ctx, DDDMR_ERR_BAD_ARG, "comm_loopback_set_peer: peer %d of %d (own rank %d)", peer_rank, world, rank);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+  HIPCHK(ctx, hipMemcpy(ctx->slots_dev + 2 * peer_rank, words, 2 * sizeof(int64_t), hipMemcpyHostToDevice));
   return DDDMR_OK;
 }
 

@@ -232,6 +232,20 @@ class LocalPlanner:
     def comm_destroy(self):
         self._check(self._lib.dddmr_rollout_comm_destroy(self._ctx))
 
+    def comm_ranks(self) -> int:
+        """Ranks the context's communicator reports (ncclCommCount); 0 without one."""
+        n = C.c_int32(0)
+        self._check(self._lib.dddmr_rollout_comm_ranks(self._ctx, C.byref(n)))
+        return int(n.value)
+
+    def comm_loopback(self):
+        """Single-device rehearsal of the exchange: see dddmr_rollout_comm_loopback."""
+        self._check(self._lib.dddmr_rollout_comm_loopback(self._ctx))
+
+    def comm_loopback_set_peer(self, peer_rank: int, words):
+        w = (C.c_int64 * 2)(int(words[0]), int(words[1]))
+        self._check(self._lib.dddmr_rollout_comm_loopback_set_peer(self._ctx, int(peer_rank), w))
+
     def stream_ceiling(self, nbytes: int = 1 << 30, reps: int = 10):
         """Measured stream ceilings of this GPU -> (copy GB/s counting read + write, read-only GB/s)."""
         cp, rd = C.c_double(0.0), C.c_double(0.0)

@@ -62,6 +62,12 @@ class MarkingLayer:
     def reset(self):
         self._lp._check(self._lp._lib.dddmr_rollout_marking_reset(self._lp._ctx))
 
+    def route_counts(self) -> dict:
+        """Updates that ran fused (four launches) / on the general route, launches of the last update."""
+        a, b, n = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self._lp._check(self._lp._lib.dddmr_rollout_marking_route_counts(self._lp._ctx, C.byref(a), C.byref(b), C.byref(n)))
+        return {"fused": int(a.value), "general": int(b.value), "launches_last_update": int(n.value)}
+
     def voxels(self) -> np.ndarray:
         n = C.c_size_t(0)
         self._lp._check(self._lp._lib.dddmr_rollout_marking_get_voxels(self._lp._ctx, None, 0, C.byref(n)))
@@ -85,7 +91,8 @@ class MarkingLayer:
         return {"updates": t["updates"], "clusters_per_update": round(t["clusters"] / n, 1),
                 "marked_per_update": round(t["marked"] / n, 1), "cleared_per_update": round(t["cleared"] / n, 1),
                 "alive_markings": int(self.last.n_alive) if self.last is not None else 0,
-                "clear_ms": round(t["clear_ms"] / n, 4), "mark_ms": round(t["mark_ms"] / n, 4)}
+                "clear_ms": round(t["clear_ms"] / n, 4), "mark_ms": round(t["mark_ms"] / n, 4),
+                "route": self.route_counts()}
 
     def close(self):
         pass      # the context owns the device state

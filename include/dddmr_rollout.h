@@ -326,6 +326,16 @@ int dddmr_rollout_comm_unique_id(uint8_t id_out[DDDMR_COMM_ID_BYTES]);
 int dddmr_rollout_comm_init(dddmr_rollout_ctx* ctx, const uint8_t id[DDDMR_COMM_ID_BYTES],
                             int32_t rank, int32_t n_ranks);
 int dddmr_rollout_comm_destroy(dddmr_rollout_ctx* ctx);
+/* Ranks of the context's exchange as the communicator itself reports them (ncclCommCount), 0 without
+   one: what a multi-GPU run prints next to its numbers. */
+int dddmr_rollout_comm_ranks(dddmr_rollout_ctx* ctx, int32_t* n_ranks_out);
+/* Single-device rehearsal of the exchange (RCCL refuses two ranks on one GPU): the context, created
+   as rank r of W, runs the same k_score -> slot vector -> resolve-kernel sequence on its stream with
+   the all-reduce replaced by a device copy of its own send vector; the peers' (cost bits, -index)
+   pairs (dddmr_rollout_winner_words of their ticks) are written into it by the host.  Exercises
+   exactly the device code a W-rank communicator runs, including ranks whose shard is empty. */
+int dddmr_rollout_comm_loopback(dddmr_rollout_ctx* ctx);
+int dddmr_rollout_comm_loopback_set_peer(dddmr_rollout_ctx* ctx, int32_t peer_rank, const int64_t words[2]);
 
 /* Per-trajectory outputs of the last tick (any pointer may be NULL). */
 int dddmr_rollout_get_debug(dddmr_rollout_ctx* ctx, dddmr_rollout_debug* dbg);
@@ -418,6 +428,12 @@ int dddmr_rollout_marking_get_voxels(dddmr_rollout_ctx* ctx, int32_t* xyz_out, s
    lethal set (lethal_map_ keys) as one byte per ground node. */
 int dddmr_rollout_marking_get_dgraph(dddmr_rollout_ctx* ctx, double* values_out, size_t capacity);
 int dddmr_rollout_marking_get_lethal(dddmr_rollout_ctx* ctx, uint8_t* flags_out, size_t capacity);
+/* Which route the updates took (observations of up to 16384 points run fused: four launches, no
+   copies; larger ones take the general route with library sorts; DDDMR_MARKING_ROUTE=general|fused
+   forces one) and how many kernels / memsets the last update launched.  Diagnostics, any pointer
+   may be NULL. */
+int dddmr_rollout_marking_route_counts(dddmr_rollout_ctx* ctx, uint32_t* updates_fused,
+                                       uint32_t* updates_general, uint32_t* launches_last_update);
 
 /* Measurement aid ("a measured stream-copy ceiling on the same GPU"): streams
    `bytes` (>= 1 GiB recommended: beyond the 256 MB of MALL) `reps` times through a float4 copy

@@ -130,6 +130,11 @@ class LocalPlanner {
     check(dddmr_rollout_comm_init(ctx_, id.data(), rank, n_ranks));
   }
   void commDestroy() { check(dddmr_rollout_comm_destroy(ctx_)); }
+  int commRanks() {
+    int32_t n = 0;
+    check(dddmr_rollout_comm_ranks(ctx_, &n));
+    return n;
+  }
   // (b) host-side exchange: min-all-reduce a 2 * n_ranks int64 vector holding every rank's winnerWords() in its
   // slots (INT64_MAX elsewhere), then resolveWords() on every rank -- exact; or the 8-byte key + resolve()
   std::array<int64_t, 2> winnerWords() const {

@@ -92,3 +92,51 @@ def test_one_rank_communicator_on_random_scenarios():
                     ra, rb = a.tick(name, tick), b.tick(name, tick)
                     assert _fields(ra) == _fields(rb)
                     np.testing.assert_array_equal(a.debug()[0], b.debug()[0])
+
+
+@pytest.mark.parametrize("world", [2, 3, 4, 7])
+@pytest.mark.parametrize("scene", ["rotate", "playground", "C1"])
+def test_loopback_exchange_every_rank_resolves_the_global_command(scene, world):
+    """The device code a W-rank communicator runs (k_score / k_empty_result -> slot vector -> k_resolve), rehearsed on one
+    GPU with dddmr_rollout_comm_loopback: every rank -- including ranks whose shard is EMPTY (the shipped rotate-in-place
+    theory has two samples, so with three or more ranks rank 0 owns none) -- must return the unsharded winner and ITS
+    command.  (an empty rank decoded the command from sample buffers it never uploaded.)"""
+    if scene == "playground":
+        sc = scenes.playground_scene()
+    else:
+        sc = scenes.bench_scene("C1")
+        if scene == "rotate":
+            sc.theory = configs.rotate_inplace_shipped("rot", shortest=True)
+    name = sc.theory.name.decode()
+    npts = max(len(sc.cloud), 16)
+    with LocalPlanner([sc.theory], max_points=npts) as whole:
+        whole.set_cloud(sc.cloud)
+        whole.setPlan(sc.plan)
+        want = whole.tick(name, sc.tick)
+    assert want.best_index >= 0
+    ranks = []
+    try:
+        for r in range(world):
+            lp = LocalPlanner([sc.theory], max_points=npts, rank=r, world_size=world)
+            lp.set_cloud(sc.cloud)
+            lp.setPlan(sc.plan)
+            ranks.append(lp)
+        words = [lp.winner_words(lp.tick(name, sc.tick)) for lp in ranks]
+        assert any(lp.last_result.n_local == 0 for lp in ranks) or scene != "rotate" or world < 3
+        for r, lp in enumerate(ranks):
+            lp.comm_loopback()
+            assert lp.comm_ranks() == world
+            for p in range(world):
+                if p != r:
+                    lp.comm_loopback_set_peer(p, words[p])
+            with pytest.raises(RolloutError):
+                lp.comm_loopback_set_peer(r, words[r])
+            for _ in range(2):
+                got = lp.tick(name, sc.tick)
+                assert (got.planner_state, got.best_index, got.best_cost) == (want.planner_state, want.best_index, want.best_cost)
+                assert (got.vx, got.vy, got.wz) == (want.vx, want.vy, want.wz), f"rank {r} of {world} (n_local {got.n_local})"
+            lp.comm_destroy()
+            assert lp.comm_ranks() == 0
+    finally:
+        for lp in ranks:
+            lp.close()

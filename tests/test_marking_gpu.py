@@ -33,6 +33,25 @@ def _vset(v):
     return set(map(tuple, np.asarray(v).tolist()))
 
 
+@pytest.fixture(autouse=True, params=["fused", "general"])
+def route(request, monkeypatch):
+    """Every test runs on both routes of dddmr_rollout_marking_update: `fused` (four launches, observations of up to
+    16384 points: csrc/marking_fused.hip.h) and `general` (library sorts, any size: csrc/marking.hip.h).  The layer
+    reads DDDMR_MARKING_ROUTE when it is created."""
+    monkeypatch.setenv("DDDMR_MARKING_ROUTE", request.param)
+    return request.param
+
+
+def _check_route(layer, n_updates):
+    want = os.environ.get("DDDMR_MARKING_ROUTE")
+    rc = layer.route_counts()
+    if want == "fused":
+        assert rc["fused"] == n_updates and rc["general"] == 0, rc
+        assert rc["launches_last_update"] <= 12, rc          # VERDICT r2 #1: <= 12 launches per update
+    elif want == "general":
+        assert rc["general"] == n_updates and rc["fused"] == 0, rc
+
+
 STATS = {"sequences": 0, "updates_compared": 0, "sequences_stopped_at_a_fragile_decision": 0, "smallest_margin_of_a_stop": None}
 
 
@@ -76,6 +95,7 @@ def _run_sequence(cfg, static_map, poses, scene_of, window=5.0, height=2.0, grou
             totals["marked"] += so.n_marked; totals["cleared"] += so.n_cleared; totals["clusters"] += so.n_clusters
             STATS["updates_compared"] += 1
         final = (len(gv), int((mo.dgraph() < cfg.max_obstacle_distance).sum()), int(mo.lethal().sum()))
+        _check_route(layer, n_updates)
         layer.reset()
         assert len(layer.voxels()) == 0 and (layer.dgraph() == cfg.max_obstacle_distance).all() and not layer.lethal().any()
     STATS["sequences"] += 1
@@ -249,3 +269,86 @@ def test_long_sequence_with_many_compactions():
 
     totals, final = _run_sequence(cfg, walls, poses, scene_of, n_updates=n, fragile_tol=1e-5)
     assert totals["marked"] > 1000 and totals["cleared"] > 100
+
+
+@pytest.mark.parametrize("n_points", [3000, 4096, 4097, 8192, 8193, 15000, 16384])
+def test_observation_sizes_of_every_fused_instantiation(n_points, route):
+    """The fused route sorts with 4, 8 or 16 elements per lane (observations of up to 4096 / 8192 / 16384 points):
+    clouds handed over with set_cloud at and around those sizes, three updates each with the robot moving."""
+    _, cloud, walls, _ = _scene()
+    rng = np.random.default_rng(n_points)
+    near = cloud[(np.abs(cloud[:, 0] - 1.0) < 5.0) & (np.abs(cloud[:, 1]) < 5.0) & (cloud[:, 2] > 0.05) & (cloud[:, 2] < 2.0)]
+    cfg = marking.shipped_config(euclidean_cluster_extraction_tolerance=0.12)
+    ground = marking.ground_lattice()
+    mo = oracle.MarkingOracle(cfg, ground, walls[:, :3])
+    sc = scenes.bench_scene("C2")
+    with LocalPlanner([sc.theory], max_points=1 << 16) as lp:
+        layer = marking.MarkingLayer(lp, cfg, ground, walls[:, :3])
+        for k in range(3):
+            pick = rng.choice(len(near), size=min(n_points, len(near)), replace=False)
+            obs = np.ascontiguousarray(near[np.sort(pick)], dtype=np.float32)
+            assert len(obs) == n_points
+            t_gb = (0.4 * k, 0.0, 0.0, 0, 0, 0, 1)
+            lp.set_cloud(obs)
+            st = layer.update(T_BS, t_gb)
+            so = mo.update(obs[:, :3], T_BS, t_gb)
+            assert (st.n_observation, st.n_clusters, st.n_marked, st.n_in_window, st.n_cleared, st.n_alive) == \
+                   (so.n_observation, so.n_clusters, so.n_marked, so.n_in_window, so.n_cleared, so.n_alive)
+            assert _vset(layer.voxels()) == _vset(mo.voxels())
+            np.testing.assert_array_equal(layer.lethal(), mo.lethal())
+            np.testing.assert_array_equal(layer.dgraph(), mo.dgraph())
+        _check_route(layer, 3)
+
+
+def test_observation_too_wide_for_the_fused_sort_keys_falls_back(monkeypatch):
+    """Points hundreds of metres apart (only a cloud handed over with set_cloud can be): the 0.2 m voxel range does
+    not fit the fused route's 28-bit sort keys, the mark phase of that update is redone on the general route --
+    results as ever, and the route counters say so."""
+    monkeypatch.setenv("DDDMR_MARKING_ROUTE", "auto")
+    _, cloud, walls, _ = _scene()
+    near = cloud[(np.abs(cloud[:, 0]) < 5.0) & (np.abs(cloud[:, 1]) < 5.0) & (cloud[:, 2] > 0.05) & (cloud[:, 2] < 2.0)][::7][:5000]
+    far = np.array([[900.0, 650.0, 40.0, 0], [900.05, 650.0, 40.0, 0], [-700.0, -820.0, -30.0, 0]], dtype=np.float32)
+    cfg = marking.shipped_config()
+    ground = marking.ground_lattice()
+    mo = oracle.MarkingOracle(cfg, ground, walls[:, :3])
+    sc = scenes.bench_scene("C2")
+    with LocalPlanner([sc.theory], max_points=1 << 16) as lp:
+        layer = marking.MarkingLayer(lp, cfg, ground, walls[:, :3])
+        for k, obs in enumerate([near, np.concatenate([near[:4000], far]), near[500:4500], np.concatenate([far, near[:3000]])]):
+            obs = np.ascontiguousarray(obs, dtype=np.float32)
+            t_gb = (0.3 * k, 0.0, 0.0, 0, 0, 0, 1)
+            lp.set_cloud(obs)
+            st = layer.update(T_BS, t_gb)
+            so = mo.update(obs[:, :3], T_BS, t_gb)
+            assert (st.n_observation, st.n_clusters, st.n_marked, st.n_in_window, st.n_cleared, st.n_alive) == \
+                   (so.n_observation, so.n_clusters, so.n_marked, so.n_in_window, so.n_cleared, so.n_alive)
+            assert _vset(layer.voxels()) == _vset(mo.voxels())
+            np.testing.assert_array_equal(layer.lethal(), mo.lethal())
+            np.testing.assert_array_equal(layer.dgraph(), mo.dgraph())
+        rc = layer.route_counts()
+        assert rc["fused"] == 2 and rc["general"] == 2, rc
+
+
+def test_observation_larger_than_the_fused_route_takes_the_general_one(monkeypatch):
+    monkeypatch.setenv("DDDMR_MARKING_ROUTE", "auto")
+    _, cloud, walls, _ = _scene()
+    near = cloud[(np.abs(cloud[:, 0]) < 6.0) & (np.abs(cloud[:, 1]) < 6.0) & (cloud[:, 2] > 0.05) & (cloud[:, 2] < 2.0)]
+    assert len(near) > 20000
+    cfg = marking.shipped_config(perception_window_size=6.0)
+    ground = marking.ground_lattice()
+    mo = oracle.MarkingOracle(cfg, ground, walls[:, :3])
+    sc = scenes.bench_scene("C2")
+    with LocalPlanner([sc.theory], max_points=1 << 16) as lp:
+        layer = marking.MarkingLayer(lp, cfg, ground, walls[:, :3])
+        for k, nobs in enumerate([20000, 9000, 17000]):
+            obs = np.ascontiguousarray(near[k::2][:nobs], dtype=np.float32)
+            t_gb = (0.2 * k, 0.0, 0.0, 0, 0, 0, 1)
+            lp.set_cloud(obs)
+            st = layer.update(T_BS, t_gb)
+            so = mo.update(obs[:, :3], T_BS, t_gb)
+            assert (st.n_observation, st.n_clusters, st.n_marked, st.n_cleared, st.n_alive) == \
+                   (so.n_observation, so.n_clusters, so.n_marked, so.n_cleared, so.n_alive)
+            assert _vset(layer.voxels()) == _vset(mo.voxels())
+            np.testing.assert_array_equal(layer.dgraph(), mo.dgraph())
+        rc = layer.route_counts()
+        assert rc["fused"] == 1 and rc["general"] == 2, rc
