@@ -132,7 +132,9 @@ struct MarkCounters {         // device counters of one update (copied back for 
   uint32_t n_dup;   // clusters of this update that found their voxel already claimed by another one (marking_fix_ties)
   uint32_t n_new_keys;   // voxels that entered the store for the first time in this update (store garbage collection)
   uint32_t n_rehashed;   // alive markings moved by this update's garbage collection
-  uint32_t fallback;     // fused route: the voxel sort keys did not fit, the mark phase has to take the general route
+  uint32_t fallback;     // fused route: a partition or its voxel sort keys did not fit, the mark phase has to take the general route
+  uint32_t n_clear;      // fused route: stored markings inside the window and the sensor's view (entries of the ray-test list)
+  uint32_t n_revived;    // fused route: markings that went from not alive to alive in the commit
 };
 
 // isinLidarObservation (:682-746).  The reference builds a rotation that turns the x axis onto the viewing
@@ -223,9 +225,7 @@ __global__ __launch_bounds__(256) void k_mk_fov(MarkParams k, MarkStore s, MarkC
 // a removed marking is recorded with it, because that route's commit may hand the slot to a new cluster in the same
 // launch that runs removePCPtr.
 __device__ __forceinline__ void mk_clear_wave(const MarkParams& k, const MarkStore& s, const PointGrid& prev, MarkCounters* __restrict__ cnt,
-                                              const uint32_t w, const int lane, uint2* __restrict__ removed_on) {
-  if (w >= k.n_alive_prev || !s.fov_flag[w]) return;
-  const uint32_t slot = s.alive_list[w];
+                                              const uint32_t slot, const int lane, uint2* __restrict__ removed_on) {
   int x, y, z;
   voxel_unkey(s.keys[slot], &x, &y, &z);
   const float px = (float)(x * k.res), py = (float)(y * k.res), pz = (float)(z * k.hres);
@@ -280,7 +280,9 @@ __device__ __forceinline__ void mk_clear_wave(const MarkParams& k, const MarkSto
   }
 }
 __global__ __launch_bounds__(256) void k_mk_clear(MarkParams k, MarkStore s, PointGrid prev, MarkCounters* __restrict__ cnt) {
-  mk_clear_wave(k, s, prev, cnt, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, nullptr);
+  const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= k.n_alive_prev || !s.fov_flag[w]) return;
+  mk_clear_wave(k, s, prev, cnt, s.alive_list[w], threadIdx.x & 63, nullptr);
 }
 
 // removePCPtr's loop over nodes_of_min_distance_, recomputed from the marking's generator points: every ground node

@@ -1,24 +1,31 @@
-// marking_fused.hip.h -- the marking / clearing update for observations of up to 16384 points in FOUR launches.
+// marking_fused.hip.h -- the marking / clearing update for observations of up to 16384 points in FIVE launches.
 //
-// The general route (marking.hip.h + rocPRIM sorts, any observation size) issues ~53 launches per update, ~30 of them
-// at the 4.5-4.9 us launch floor, plus three mid-update copies: for the 6 k-point observation of a 16-line LiDAR the
-// update is launch-bound (profiles/r02_C5M_kernel_stats.csv).  Here every grouping step (the three stable sorts, their
-// flag / scan / reduce rounds, the per-cluster stages, the hash insert and the commit) runs inside ONE 1024-lane
-// workgroup with the sort keys in registers and the exchange buffers in LDS, and the chip-wide steps share launches
-// with each other:
+// The general route (marking.hip.h + rocPRIM sorts, any observation size) issues ~55 launches per update, ~30 of them
+// at the 4.5-4.9 us launch floor, plus three mid-update copies: for the observation of a 16-line LiDAR the update is
+// launch-bound (profiles/r02_C5M_kernel_stats.csv).  Here the chip-wide steps share launches, and everything between
+// the union-find and the dGraph update -- three stable sorts with their flag / scan / reduce rounds, the per-cluster
+// tests, the hash insert -- runs in 64 independent 256-lane workgroups, each on the clusters whose seed point hashes
+// to it, with points, sort keys and payloads resident in LDS:
 //
-//   launch 1  k_mkf_pre             block 0: grid of the new observation (zero, count, scan, scatter: one workgroup)
-//                                   blocks 1..: window + field-of-view test of every stored marking
-//   launch 2  k_mkf_clear_cc        selfClear ray tests (a wave per marking)  |  Euclidean clustering (union-find)
-//   launch 3  k_mkf_unmark_groups   block 0: clusters -> centroids -> 0.2 m VoxelGrid -> static / FOV tests ->
-//                                   projection + 0.1 m VoxelGrid -> store slots -> commit
-//                                   blocks 1..: removePCPtr of the markings launch 2 cleared
-//   launch 4  k_mkf_dgraph_finish   dGraph / lethal update of the new generator points  |  next update's alive list;
-//                                   the last block publishes the counters to host-mapped memory and zeroes them
+//   launch 1  k_mkf_pre             block 0: grid of the new observation, built in LDS by one workgroup
+//                                   blocks 1..: every store slot: window + field-of-view test -> list of ray tests
+//   launch 2  k_mkf_clear_cc        selfClear ray tests (a wave per listed marking)  |  Euclidean clustering (union-find)
+//   launch 3  k_mkf_roots           every point's cluster seed (root of the union-find)
+//   launch 4  k_mkf_groups          blocks 0..63: partition p = clusters with hash(seed) = p: centroids -> 0.2 m
+//                                   VoxelGrid -> static / FOV tests -> projection + 0.1 m VoxelGrid -> store slots
+//                                   blocks 64..: removePCPtr of the markings launch 2 cleared
+//   launch 5  k_mkf_commit_dgraph   keeper of every claimed voxel -> pool  |  dGraph / lethal update of the new
+//                                   generator points; the last block publishes the counters to host-mapped memory
+//
+// (A first version ran the grouping chain in ONE 1024-lane workgroup with the keys in registers: 670 us at 10.5 k
+// points -- a wave64 VALU instruction occupies its SIMD for four cycles and one CU is 1/256 of the chip; the phase
+// stamps of tools/marking_stamps.py showed every step, not only the sorts, waiting on that one CU.)
 //
 // What each step computes, and the reference lines it follows, is unchanged from marking.hip.h: the same float
 // operations in the same order (cluster / voxel centroids are sequential float sums in point-index order, which is
-// why the sorts must be stable), so both routes give bit-identical stores, dGraphs and lethal sets.
+// why the sorts must be stable), so both routes give bit-identical stores, dGraphs and lethal sets.  A cluster is
+// named by its seed's point index here (marking.hip.h: by its rank among the seeds): the same order, which is all
+// the contested-voxel priority looks at.
 #pragma once
 #include "marking.hip.h"
 
@@ -26,18 +33,27 @@
 
 namespace dddmr {
 
-constexpr int kFuseThreads = 1024;
-constexpr uint32_t kFuseMaxObs = 16384;      // points of an observation the fused route takes (16 per lane)
-constexpr uint32_t kFuseMaxCells = 32768;    // cells of the observation grid one workgroup scans
-constexpr int kFuseKeyBits = 28;             // voxel sort keys: 4 passes of 7 bits at most (sentinel = all ones)
+constexpr uint32_t kFuseMaxObs = 16384;      // points of an observation the fused route takes
+constexpr uint32_t kFuseMaxCells = 32768;    // cells of the observation grid (16-bit counters, two per LDS word)
+constexpr int kFuseParts = 64;               // partitions of the clusters (by hash of the seed point index)
+constexpr uint32_t kPartCap = 4096;          // points one partition workgroup takes (16 per lane)
+constexpr int kPartThreads = 256;
+constexpr int kFuseKeyBits = 28;             // voxel sort keys: 4 passes of 7 bits at most
+
+#ifdef DDDMR_PHASE_STAMPS
+// diagnostic build only: s_memtime at the phase boundaries of partition 0 and of the grid block (tools/marking_stamps.py)
+__device__ unsigned long long g_mk_stamps[64];
+#define MKF_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_mk_stamps[i] = (unsigned long long)clock64(); } while (0)
+#else
+#define MKF_STAMP(i) do { } while (0)
+#endif
 
 struct FuseBufs {
   const float4* pts;       // this update's observation (global frame)
-  uint32_t* parent;        // [n] union-find
-  float4* spts;            // [n] observation in cluster order (sort 1)
-  float4* ds;              // [n] 0.2 m voxel centroids, w = cluster
+  uint32_t* parent;        // [n] union-find; after k_mkf_roots: every point's seed
+  float4* ds;              // [n] 0.2 m voxel centroids, w = cluster (scratch of a partition between its two halves)
   float4* gen;             // [n] generator points, w = cluster
-  uint32_t* pool_ofs;      // [n] per cluster: first pool entry of its generator points, ~0 = not the keeper
+  uint32_t* clear_list;    // [table] slots inside the window and the sensor's view
   uint2* removed_on;       // [table] (pool offset, count) of the markings this update's selfClear removed
   uint32_t* ticket;        // [2]
   MarkCounters* host_out;  // host-mapped copy of the update's counters
@@ -50,8 +66,14 @@ __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long*
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+__device__ __forceinline__ uint32_t part_of(uint32_t seed) { return (seed * 2654435761u) >> 26; }   // 64 partitions
+__device__ __forceinline__ int bits_for(int range) { return range <= 0 ? 1 : 32 - __clz(range); }
 
-// exclusive prefix of one value per lane over the 1024-lane block, in lane order (two barriers; wsum = 16 LDS words)
+// exclusive prefix of one value per lane over a block of W waves, in lane order (two barriers; wsum = W LDS words)
+template <int W>
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, uint32_t* total) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t incl = wave_incl_scan_u32(v);
@@ -59,7 +81,7 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, 
   __syncthreads();
   uint32_t base = 0, tot = 0;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
+  for (int j = 0; j < W; ++j) {
     const uint32_t x = wsum[j];
     tot += x;
     if (j < w) base += x;
@@ -69,213 +91,111 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* wsum, 
   return base + incl - v;
 }
 
-// The block's elements live in registers, E per lane, "wave-blocked": position = wave * 64 E + slot * 64 + lane.
-template <int E>
-__device__ __forceinline__ uint32_t fpos(int s) {
-  return (uint32_t)((threadIdx.x >> 6) * 64 * E + s * 64 + (threadIdx.x & 63));
-}
-// exclusive prefix over positions of one flag per element (bit s of `flags` = slot s)
-template <int E>
-__device__ __forceinline__ void pos_excl_scan(const uint32_t flags, uint32_t (&ex)[E], uint32_t* wsum, uint32_t* total) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  uint32_t carry = 0;
-#pragma unroll
-  for (int s = 0; s < E; ++s) {
-    const unsigned long long b = __ballot(((flags >> s) & 1u) != 0u);
-    ex[s] = carry + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-    carry += (uint32_t)__popcll(b);
-  }
-  if (lane == 0) wsum[w] = carry;
-  __syncthreads();
-  uint32_t base = 0, tot = 0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const uint32_t x = wsum[j];
-    tot += x;
-    if (j < w) base += x;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < E; ++s) ex[s] += base;
-  *total = tot;
-}
-
-// One stable LSD radix pass over a 7-bit digit.  Ranking: the lanes of a wave that hold the same digit find each
-// other with seven ballots (their rank among themselves = lanes below in the match mask), a per-wave histogram
-// column in LDS carries the count over the wave's slots, one block scan over (digit, wave) turns the columns into
-// bases.  Keys and payloads go through the LDS exchange buffers and come back in position order, so after the pass
-// xk / xp also hold the whole sorted sequence.  Keys of all ones keep to the end (digit 127 at every shift < 22).
-template <int E>
-__device__ __forceinline__ void radix_pass(uint32_t (&key)[E], uint32_t (&pay)[E], const int shift, uint32_t* hist, uint32_t* xk,
-                                           uint16_t* xp, uint32_t* wsum) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  hist[tid] = 0u;
-  hist[tid + 1024] = 0u;
-  __syncthreads();
-  uint32_t rank[E];
-#pragma unroll
-  for (int s = 0; s < E; ++s) {
-    const uint32_t d = (key[s] >> shift) & 127u;
-    unsigned long long m = ~0ull;
-#pragma unroll
-    for (int b = 0; b < 7; ++b) {
-      const bool bit = ((d >> b) & 1u) != 0u;
-      const unsigned long long bal = __ballot(bit);
-      m &= bit ? bal : ~bal;
-    }
-    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-    const uint32_t pre = hist[d * 16 + w];
-    rank[s] = pre + below;
-    __builtin_amdgcn_wave_barrier();
-    if (below == 0u) hist[d * 16 + w] = pre + (uint32_t)__popcll(m);
-    __builtin_amdgcn_wave_barrier();
-  }
-  __syncthreads();
-  {
-    const uint32_t a = hist[2 * tid], b = hist[2 * tid + 1];
-    uint32_t tot;
-    const uint32_t ex = block_excl_scan(a + b, wsum, &tot);
-    hist[2 * tid] = ex;
-    hist[2 * tid + 1] = ex + a;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < E; ++s) {
-    const uint32_t d = (key[s] >> shift) & 127u;
-    const uint32_t p = hist[d * 16 + w] + rank[s];
-    xk[p] = key[s];
-    xp[p] = (uint16_t)pay[s];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < E; ++s) {
-    const uint32_t p = fpos<E>(s);
-    key[s] = xk[p];
-    pay[s] = xp[p];
-  }
-  (void)lane;
-}
-
-// block-wide minimum / maximum of three ints (red = 6 * 16 LDS ints)
-__device__ __forceinline__ void block_minmax3(int (&mn)[3], int (&mx)[3], int* red) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
-      mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
-    }
-  }
-  if (lane == 0) {
-#pragma unroll
-    for (int a = 0; a < 3; ++a) { red[a * 16 + w] = mn[a]; red[(3 + a) * 16 + w] = mx[a]; }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    int lo = red[a * 16], hi = red[(3 + a) * 16];
-#pragma unroll
-    for (int j = 1; j < 16; ++j) { lo = min(lo, red[a * 16 + j]); hi = max(hi, red[(3 + a) * 16 + j]); }
-    mn[a] = lo;
-    mx[a] = hi;
-  }
-  __syncthreads();
-}
-__device__ __forceinline__ int bits_for(int range) { return range <= 0 ? 1 : 32 - __clz(range); }
-
 // ProjectInliers(SACMODEL_PLANE) of one point (cluster_marking.cpp:54-64; k_mk_proj_keys)
-__device__ __forceinline__ void project_on_base_plane(const MarkParams& k, const float4 p, float* qx, float* qy, float* qz) {
+__device__ __forceinline__ void project_on_base_plane(const MarkParams& k, float x, float y, float z, float* qx, float* qy, float* qz) {
   float m0 = k.mc[0], m1 = k.mc[1], m2 = k.mc[2], m3 = 0.0f;
   const float nrm = sqrtf((m0 * m0 + m2 * m2) + (m1 * m1 + m3 * m3));
   m0 = m0 / nrm; m1 = m1 / nrm; m2 = m2 / nrm;
-  const float dist = (m0 * p.x + m2 * p.z) + (m1 * p.y + k.mc[3] * 1.0f);
-  *qx = p.x - m0 * dist; *qy = p.y - m1 * dist; *qz = p.z - m2 * dist;
+  const float dist = (m0 * x + m2 * z) + (m1 * y + k.mc[3] * 1.0f);
+  *qx = x - m0 * dist; *qy = y - m1 * dist; *qz = z - m2 * dist;
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 1, block 0: uniform grid of the observation built by one workgroup (<= 16384 points, <= 32768 cells)
+// launch 1, block 0: uniform grid of the observation (<= 16384 points, <= 32768 cells) built by one workgroup with
+// the cell counters in LDS (16 bits each, two per word: the count pass and the scan never leave the CU)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void fuse_build_grid(PointGrid g, const float4* __restrict__ pts, uint32_t* __restrict__ parent,
-                                                uint32_t* wsum) {
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const uint32_t n = g.n, cells1 = (uint32_t)(g.nx * g.ny * g.nz) + 1u;
-  for (uint32_t j = tid; j < cells1; j += kFuseThreads) g.cell_start[j] = 0u;
-  __threadfence();
+                                                uint32_t* cnt2 /* [16384] */, uint32_t* wsum) {
+  const int tid = threadIdx.x;
+  const uint32_t n = g.n, cells = (uint32_t)(g.nx * g.ny * g.nz);
+  MKF_STAMP(32);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) cnt2[j * 1024 + tid] = 0u;
   __syncthreads();
   uint32_t cell[16], rk[16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    const uint32_t i = (uint32_t)s * kFuseThreads + tid;
+    const uint32_t i = (uint32_t)s * 1024u + tid;
     cell[s] = 0u; rk[s] = 0u;
     if (i < n) {
       const float4 p = pts[i];
       cell[s] = (uint32_t)((grid_cz(g, p.z) * g.ny + grid_cy(g, p.y)) * g.nx + grid_cx(g, p.x));
-      rk[s] = atomicAdd(&g.cell_start[cell[s]], 1u);
+      const uint32_t sh = (cell[s] & 1u) * 16u;
+      rk[s] = (atomicAdd(&cnt2[cell[s] >> 1], 1u << sh) >> sh) & 0xFFFFu;
       parent[i] = i;
     }
   }
-  __threadfence();
   __syncthreads();
-  // in-place exclusive scan: wave w owns the cells [w R, (w + 1) R), 64 consecutive cells per step
-  const uint32_t R = (((cells1 + 15u) / 16u) + 63u) & ~63u;
-  const uint32_t lo = min((uint32_t)w * R, cells1), hi = min(lo + R, cells1);
-  uint32_t acc = 0;
-  for (uint32_t j = lo + lane; j < hi; j += 64) acc += ld_agent(&g.cell_start[j]);
+  MKF_STAMP(33);
+  // exclusive scan: lane t owns the cells [32 t, 32 t + 32) = 16 words
+  uint32_t wv[16], sum = 0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += (uint32_t)__shfl_xor((int)acc, o, 64);
-  if (lane == 0) wsum[w] = acc;
-  __syncthreads();
-  uint32_t carry = 0;
-  for (int j = 0; j < w; ++j) carry += wsum[j];
-  for (uint32_t j0 = lo; j0 < hi; j0 += 64) {        // (wave-uniform trip count)
-    const uint32_t j = j0 + lane;
-    const uint32_t v = j < hi ? ld_agent(&g.cell_start[j]) : 0u;
-    const uint32_t incl = wave_incl_scan_u32(v);
-    if (j < hi) g.cell_start[j] = carry + incl - v;
-    carry += wave_last(incl);
+  for (int j = 0; j < 16; ++j) {
+    wv[j] = cnt2[tid * 16 + j];
+    sum += (wv[j] & 0xFFFFu) + (wv[j] >> 16);
   }
-  __threadfence();
+  uint32_t tot;
+  uint32_t run = block_excl_scan<16>(sum, wsum, &tot);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t a = wv[j] & 0xFFFFu, b = wv[j] >> 16;
+    const uint32_t c0 = (uint32_t)tid * 32u + 2u * j;
+    if (c0 < cells) g.cell_start[c0] = run;
+    if (c0 + 1 < cells) g.cell_start[c0 + 1] = run + a;
+    cnt2[tid * 16 + j] = run | ((run + a) << 16);              // (starts <= 16384 fit 16 bits)
+    run += a + b;
+  }
+  if (tid == 0) g.cell_start[cells] = n;
   __syncthreads();
+  MKF_STAMP(34);
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
-    const uint32_t i = (uint32_t)s * kFuseThreads + tid;
+    const uint32_t i = (uint32_t)s * 1024u + tid;
     if (i < n) {
       const float4 p = pts[i];
-      g.sorted[ld_agent(&g.cell_start[cell[s]]) + rk[s]] = make_float4(p.x, p.y, p.z, __int_as_float((int)i));
+      const uint32_t st = (cnt2[cell[s] >> 1] >> ((cell[s] & 1u) * 16u)) & 0xFFFFu;
+      g.sorted[st + rk[s]] = make_float4(p.x, p.y, p.z, __int_as_float((int)i));
     }
   }
+  MKF_STAMP(35);
 }
 
-__global__ __launch_bounds__(kFuseThreads) void k_mkf_pre(MarkParams k, MarkStore s, PointGrid obs, const float4* __restrict__ pts,
-                                                          uint32_t* __restrict__ parent, MarkCounters* __restrict__ cnt) {
+__global__ __launch_bounds__(1024) void k_mkf_pre(MarkParams k, MarkStore s, PointGrid obs, FuseBufs fb, MarkCounters* __restrict__ cnt) {
+  __shared__ uint32_t cnt2[16384];
   __shared__ uint32_t wsum[16];
   if (blockIdx.x == 0) {
-    if (k.n_obs > 5u) fuse_build_grid(obs, pts, parent, wsum);
+    if (k.n_obs > 5u) fuse_build_grid(obs, fb.pts, fb.parent, cnt2, wsum);
     return;
   }
-  // window + field-of-view test of every stored marking (k_mk_fov), one lane each
-  const uint32_t w = (blockIdx.x - 1u) * kFuseThreads + threadIdx.x;
-  uint32_t flag = 0, inwin = 0;
-  if (w < k.n_alive_prev) {
-    const uint32_t slot = s.alive_list[w];
+  // every slot of the store: no owner yet in this update; alive markings get the window + field-of-view test of
+  // k_mk_fov, one lane each (the double asin / atan2 cost a wave as much as a lane); those inside go on the ray-test list
+  const uint32_t slot = (blockIdx.x - 1u) * 1024u + threadIdx.x;
+  bool inwin = false, inview = false;
+  if (slot <= k.table_mask) {
+    s.owner[slot] = 0ull;
     if (s.alive[slot]) {
       int x, y, z;
       voxel_unkey(s.keys[slot], &x, &y, &z);
+      // map iteration lower_bound(min) .. lower_bound(max): keys in [min, max) on every axis (:487-516)
       if (!(x < k.wx0 || x >= k.wx1 || y < k.wy0 || y >= k.wy1 || z < k.wz0 || z >= k.wz1)) {
-        inwin = 1;
+        inwin = true;
         const float px = (float)(x * k.res), py = (float)(y * k.res), pz = (float)(z * k.hres);
-        flag = in_lidar_observation(k, px, py, pz) ? 1u : 0u;
+        inview = in_lidar_observation(k, px, py, pz);          // outside the sensor's view: stays (:531-540)
       }
     }
-    s.fov_flag[w] = flag;
   }
-  const unsigned long long b = __ballot(inwin != 0u);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(&cnt->n_in_window, (uint32_t)__popcll(b));
+  const unsigned long long bw = __ballot(inwin), bv = __ballot(inview);
+  uint32_t base = 0;
+  if ((threadIdx.x & 63) == 0) {
+    if (bw) atomicAdd(&cnt->n_in_window, (uint32_t)__popcll(bw));
+    if (bv) base = atomicAdd(&cnt->n_clear, (uint32_t)__popcll(bv));
+  }
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  if (inview) fb.clear_list[base + lanes_below(bv)] = slot;
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 2: selfClear (a wave per marking in view)  |  Euclidean clustering, four lanes per point
+// launch 2: selfClear (a wave per listed marking)  |  Euclidean clustering, four lanes per point
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void cc_union_pair(uint32_t* parent, uint32_t i, uint32_t j) {
   uint32_t u = cc_find(parent, i), v = cc_find(parent, j);
@@ -288,11 +208,11 @@ __device__ __forceinline__ void cc_union_pair(uint32_t* parent, uint32_t i, uint
   }
 }
 
-__global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s, PointGrid prev, PointGrid obs,
-                                                      const float4* __restrict__ pts, uint32_t* parent, uint2* __restrict__ removed_on,
+__global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s, PointGrid prev, PointGrid obs, FuseBufs fb,
                                                       MarkCounters* __restrict__ cnt, uint32_t nb_clear) {
   if (blockIdx.x < nb_clear) {
-    mk_clear_wave(k, s, prev, cnt, blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63, removed_on);
+    const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w < cnt->n_clear) mk_clear_wave(k, s, prev, cnt, fb.clear_list[w], threadIdx.x & 63, fb.removed_on);
     return;
   }
   // pcl::extractEuclideanClusters as connected components (k_mk_cc_union); the (z, y) rows of a point's tolerance box
@@ -301,7 +221,7 @@ __global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s,
   const uint32_t i = t >> 2;
   const int sub = (int)(t & 3u);
   if (i >= k.n_obs) return;
-  const float4 p = pts[i];
+  const float4 p = fb.pts[i];
   const float r = k.tol + 1e-4f;
   const int x0 = grid_cx(obs, p.x - r), x1 = grid_cx(obs, p.x + r);
   const int y0 = grid_cy(obs, p.y - r), y1 = grid_cy(obs, p.y + r);
@@ -313,9 +233,22 @@ __global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s,
     for (uint32_t q = b; q < e; ++q) {
       const float4 o = obs.sorted[q];
       const uint32_t j = (uint32_t)__float_as_int(o.w);
-      if (j < i && l2_simple(o.x, o.y, o.z, p.x, p.y, p.z) < k.tol2) cc_union_pair(parent, i, j);
+      if (j < i && l2_simple(o.x, o.y, o.z, p.x, p.y, p.z) < k.tol2) cc_union_pair(fb.parent, i, j);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch 3: every point's seed (the smallest point index of its component = the point PCL starts the cluster from);
+// the per-cluster records of every point index start empty (a cluster is named by its seed's index)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mkf_roots(uint32_t n, uint32_t* parent, ClusterArrays c) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t r = cc_find(parent, i);
+  __hip_atomic_store(&parent[i], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (an ancestor at any time: safe for the finds of others)
+  c.size[i] = 0u;
+  c.state[i] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -371,201 +304,320 @@ __device__ __forceinline__ void fuse_unmark_wave(const MarkParams& k, const Mark
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 3, block 0: everything between the union-find and the dGraph update, one workgroup
+// launch 4, blocks 0..63: one partition of the clusters, everything in LDS
 // ---------------------------------------------------------------------------------------------
-template <int E>
-constexpr size_t fuse_groups_lds_bytes() {
-  return (size_t)1024 * E * (4 + 2 + 2 + 1) + 2048 * 4 + 16 * 4 + 96 * 4;
+struct PartLds {              // carve-up of the dynamic LDS of a partition workgroup
+  float *px, *py, *pz;        // [P] the partition's points (index order); second half: projected 0.2 m voxel centroids
+  uint32_t *ka, *kb;          // [P] sort keys, ping-pong; the free one holds the voxel key by sorted position
+  uint16_t *pa, *pb;          // [P] payloads, ping-pong
+  uint16_t* rk;               // [P + 2] rank scratch of a pass; group index by sorted position
+  uint16_t* start;            // [P + 2] first sorted position of a cluster
+  uint16_t* mine;             // [P] observation index of a local point
+  uint16_t* lcid;             // [P] local cluster of a local point / of a voxel centroid
+  uint16_t* gci;              // [P] local cluster -> its seed's observation index
+  uint8_t* state;             // [P] per local cluster
+  uint32_t* hist;             // [4 * 128]
+  uint32_t* wsum;             // [4]
+  int* red;                   // [24]
+  uint32_t* misc;             // [8]
+};
+constexpr size_t kPartLdsBytes = (size_t)kPartCap * (12 + 8 + 4 + 2 + 2 + 2 + 2 + 2 + 1) + 8 + 512 * 4 + 4 * 4 + 24 * 4 + 8 * 4 + 64;
+
+__device__ __forceinline__ PartLds part_lds(unsigned char* lds) {
+  PartLds L;
+  constexpr uint32_t P = kPartCap;
+  L.px = reinterpret_cast<float*>(lds); L.py = L.px + P; L.pz = L.py + P;
+  L.ka = reinterpret_cast<uint32_t*>(L.pz + P); L.kb = L.ka + P;
+  L.hist = L.kb + P; L.wsum = L.hist + 512; L.red = reinterpret_cast<int*>(L.wsum + 4); L.misc = reinterpret_cast<uint32_t*>(L.red + 24);
+  L.pa = reinterpret_cast<uint16_t*>(L.misc + 8); L.pb = L.pa + P;
+  L.rk = L.pb + P; L.start = L.rk + P + 2; L.mine = L.start + P + 2; L.lcid = L.mine + P; L.gci = L.lcid + P;
+  L.state = reinterpret_cast<uint8_t*>(L.gci + P);
+  return L;
 }
 
-template <int E>
-__device__ __forceinline__ void fuse_groups(const MarkParams& k, const FuseBufs& fb, ClusterArrays c, MarkStore s, const PointGrid& ground,
-                            const PointGrid& map, uint32_t n_map, MarkCounters* __restrict__ cnt, unsigned char* lds) {
-  constexpr uint32_t N = 1024u * E;
-  uint32_t* xk = reinterpret_cast<uint32_t*>(lds);              // [N] key exchange / voxel key by position
-  uint16_t* xp = reinterpret_cast<uint16_t*>(xk + N);           // [N] payload exchange = the sorted sequence
-  uint16_t* cid = xp + N;                                       // [N] cluster of a point, later of a 0.2 m voxel
-  uint8_t* state = reinterpret_cast<uint8_t*>(cid + N);         // [N] per cluster
-  uint32_t* hist = reinterpret_cast<uint32_t*>(state + N);      // [2048]
-  uint32_t* wsum = hist + 2048;                                 // [16]
-  int* red = reinterpret_cast<int*>(wsum + 16);                 // [96]
-  uint16_t* rootcid = reinterpret_cast<uint16_t*>(xk);          // [N]     alias, G0 only
-  uint16_t* start = reinterpret_cast<uint16_t*>(xk);            // [N + 1] alias, G1..G2
-
-  const int tid = threadIdx.x;
-  const uint32_t n = k.n_obs;
-  uint32_t key[E], pay[E];
-
-  // ---- G0: roots -> cluster ids in seed order (root = smallest point index = PCL's seed) ----
-  uint32_t nc;
-  {
-    uint32_t root[E], ex[E], isr = 0u;
+// block-wide minimum / maximum of three ints over 4 waves (red = 24 LDS ints)
+__device__ __forceinline__ void block_minmax3(int (&mn)[3], int (&mx)[3], int* red) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
 #pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      const uint32_t i = fpos<E>(s_);
-      root[s_] = i < n ? cc_find(fb.parent, i) : 0xFFFFFFFFu;
-      if (i < n && root[s_] == i) isr |= 1u << s_;
-    }
-    pos_excl_scan<E>(isr, ex, wsum, &nc);
+  for (int a = 0; a < 3; ++a) {
 #pragma unroll
-    for (int s_ = 0; s_ < E; ++s_)
-      if ((isr >> s_) & 1u) rootcid[fpos<E>(s_)] = (uint16_t)ex[s_];
-    __syncthreads();
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      const uint32_t i = fpos<E>(s_);
-      key[s_] = 0xFFFFFFFFu; pay[s_] = 0u;
-      if (i < n) {
-        const uint32_t cv = rootcid[root[s_]];
-        cid[i] = (uint16_t)cv;
-        key[s_] = cv; pay[s_] = i;
-      }
-    }
-    __syncthreads();
-  }
-  // ---- G1: sort 1 = clusters in seed order, their points in index order (stable by cluster id) ----
-  radix_pass<E>(key, pay, 0, hist, xk, xp, wsum);
-  if (nc > 128u) radix_pass<E>(key, pay, 7, hist, xk, xp, wsum);
-  __syncthreads();                                               // xk is free: cluster starts
-#pragma unroll
-  for (int s_ = 0; s_ < E; ++s_) {
-    const uint32_t m = fpos<E>(s_);
-    if (m < n) {
-      const uint32_t prev = m ? (uint32_t)cid[xp[m - 1]] : 0xFFFFFFFFu;
-      if (key[s_] != prev) start[key[s_]] = (uint16_t)m;
-      fb.spts[m] = fb.pts[pay[s_]];
+    for (int o = 32; o > 0; o >>= 1) {
+      mn[a] = min(mn[a], __shfl_xor(mn[a], o, 64));
+      mx[a] = max(mx[a], __shfl_xor(mx[a], o, 64));
     }
   }
-  if (tid == 0) start[nc] = (uint16_t)n;
-  __threadfence();
+  if (lane == 0) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { red[a * 4 + w] = mn[a]; red[12 + a * 4 + w] = mx[a]; }
+  }
   __syncthreads();
-  // ---- G2: per cluster centroid (floats added in index order, / size), min size, "centre attached to the ground" ----
-  {
-    uint32_t kept = 0;
-    for (uint32_t ci = tid; ci < nc; ci += kFuseThreads) {
-      const uint32_t b = start[ci], e = start[ci + 1];
-      float cx = 0.f, cy = 0.f, cz = 0.f;
-      uint32_t m = b;
-      for (; m + 4 <= e; m += 4) {
-        const float4 p0 = fb.spts[m], p1 = fb.spts[m + 1], p2 = fb.spts[m + 2], p3 = fb.spts[m + 3];
-        cx += p0.x; cy += p0.y; cz += p0.z;
-        cx += p1.x; cy += p1.y; cz += p1.z;
-        cx += p2.x; cy += p2.y; cz += p2.z;
-        cx += p3.x; cy += p3.y; cz += p3.z;
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    mn[a] = min(min(red[a * 4], red[a * 4 + 1]), min(red[a * 4 + 2], red[a * 4 + 3]));
+    mx[a] = max(max(red[12 + a * 4], red[12 + a * 4 + 1]), max(red[12 + a * 4 + 2], red[12 + a * 4 + 3]));
+  }
+  __syncthreads();
+}
+
+// One stable LSD radix pass over a 7-bit digit of m keys in LDS (kin / pin -> kout / pout).  Sorted position p belongs
+// to wave p / (64 E), E = elements per lane.  The lanes of a wave that hold the same digit find each other with seven
+// ballots (rank among themselves = lanes below in the match mask); a per-wave histogram column carries the count over
+// the wave's rounds; one block scan over (digit, wave) turns the columns into bases.
+__device__ __forceinline__ void lds_radix_pass(const uint32_t m, const int shift, const uint32_t* kin, const uint16_t* pin, uint32_t* kout,
+                                               uint16_t* pout, uint16_t* rk, uint32_t* hist, uint32_t* wsum) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t E = (m + 255u) / 256u;
+  hist[tid] = 0u;
+  hist[tid + 256] = 0u;
+  __syncthreads();
+  for (uint32_t s = 0; s < E; ++s) {
+    const uint32_t p = (uint32_t)w * 64u * E + s * 64u + (uint32_t)lane;
+    if (p < m) {
+      const uint32_t d = (kin[p] >> shift) & 127u;
+      unsigned long long mm = __ballot(true);
+#pragma unroll
+      for (int b = 0; b < 7; ++b) {
+        const bool bit = ((d >> b) & 1u) != 0u;
+        const unsigned long long bal = __ballot(bit);
+        mm &= bit ? bal : ~bal;
       }
-      for (; m < e; ++m) {
-        const float4 p = fb.spts[m];
-        cx += p.x; cy += p.y; cz += p.z;
-      }
-      const float sz = (float)(e - b);
-      cx /= sz; cy /= sz; cz /= sz;
-      c.size[ci] = e - b;
-      c.centroid[ci] = make_float4(cx, cy, cz, 0.f);
-      c.ds_count[ci] = 0;
-      c.gen_count[ci] = 0;
-      c.gen_first[ci] = 0xFFFFFFFFu;
-      bool ok = (int)(e - b) >= k.min_cluster;
-      if (ok) ++kept;
-      if (ok && grid_radius_count(ground, cx, cy, cz, 0.05f + 1e-4f, static_cast<float>(0.05 * 0.05), 1) > 0) ok = false;
-      state[ci] = ok ? 1u : 0u;
+      const uint32_t below = lanes_below(mm);
+      const uint32_t pre = hist[w * 128 + d];
+      rk[p] = (uint16_t)(pre + below);
+      __builtin_amdgcn_wave_barrier();
+      if (below == 0u) hist[w * 128 + d] = pre + (uint32_t)__popcll(mm);
     }
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  {
+    // entry j = digit * 4 + wave; lane t scans j = 2 t, 2 t + 1
+    const uint32_t j0 = 2u * tid, j1 = j0 + 1u;
+    const uint32_t a0 = (j0 & 3u) * 128u + (j0 >> 2), a1 = (j1 & 3u) * 128u + (j1 >> 2);
+    const uint32_t a = hist[a0], b = hist[a1];
     uint32_t tot;
-    (void)block_excl_scan(kept, wsum, &tot);
-    if (tid == 0) { cnt->n_clusters = nc; cnt->n_clusters_kept = tot; }
-    __threadfence();
+    const uint32_t ex = block_excl_scan<4>(a + b, wsum, &tot);
+    hist[a0] = ex;
+    hist[a1] = ex + a;
+  }
+  __syncthreads();
+  for (uint32_t s = 0; s < E; ++s) {
+    const uint32_t p = (uint32_t)w * 64u * E + s * 64u + (uint32_t)lane;
+    if (p < m) {
+      const uint32_t key = kin[p];
+      const uint32_t dst = hist[w * 128 + ((key >> shift) & 127u)] + rk[p];
+      kout[dst] = key;
+      pout[dst] = pin[p];
+    }
+  }
+  __syncthreads();
+}
+
+// stable sort of (key, payload) pairs on the key bits [0, nbits): the current buffers are swapped pass by pass
+__device__ __forceinline__ void lds_radix_sort(const uint32_t m, const int nbits, uint32_t*& kc, uint16_t*& pc, uint32_t*& kf, uint16_t*& pf,
+                                               uint16_t* rk, uint32_t* hist, uint32_t* wsum) {
+  for (int sh = 0; sh < nbits; sh += 7) {
+    lds_radix_pass(m, sh, kc, pc, kf, pf, rk, hist, wsum);
+    uint32_t* tk = kc; kc = kf; kf = tk;
+    uint16_t* tp = pc; pc = pf; pf = tp;
+  }
+}
+
+// groups of equal (cluster, voxel) runs in a sorted sequence of m elements: kc = cluster by position, vk = voxel key by
+// position.  rk[j] = number of group starts before position j (rk[m] = groups), returns the number of groups.
+__device__ __forceinline__ uint32_t lds_group_index(const uint32_t m, const uint32_t* kc, const uint32_t* vk, const uint8_t* state, const bool all,
+                                                    uint16_t* rk, uint32_t* wsum) {
+  uint32_t run = 0;
+  for (uint32_t j0 = 0; j0 < m; j0 += 256) {
+    const uint32_t j = j0 + threadIdx.x;
+    uint32_t fl = 0;
+    if (j < m && (all || state[kc[j]] != 0u)) fl = (j == 0u || kc[j - 1] != kc[j] || vk[j - 1] != vk[j]) ? 1u : 0u;
+    uint32_t tot;
+    const uint32_t ex = block_excl_scan<4>(fl, wsum, &tot);
+    if (j < m) rk[j] = (uint16_t)(run + ex);
+    run += tot;
+  }
+  if (threadIdx.x == 0) rk[m] = (uint16_t)run;
+  __syncthreads();
+  return run;
+}
+
+__device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBufs& fb, ClusterArrays c, MarkStore s, const PointGrid& ground,
+                                               const PointGrid& map, uint32_t n_map, MarkCounters* __restrict__ cnt, unsigned char* lds) {
+  constexpr uint32_t P = kPartCap;
+  PartLds L = part_lds(lds);
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t n = k.n_obs, part = blockIdx.x;
+  uint32_t *kc = L.ka, *kf = L.kb;
+  uint16_t *pc = L.pa, *pf = L.pb;
+  MKF_STAMP(0);
+  // ---- P0: the partition's points, in index order.  Every wave scans a quarter of the seeds; what it selects goes to
+  //      its own staging list first (ka | kb as 4 x P shorts), the four lists are then concatenated ----
+  uint32_t m;
+  {
+    uint16_t* stage = reinterpret_cast<uint16_t*>(L.ka) + (size_t)w * P;
+    const uint32_t chunk = (((n + 3u) / 4u) + 63u) & ~63u;
+    const uint32_t lo = min((uint32_t)w * chunk, n), hi = min(lo + chunk, n);
+    uint32_t have = 0;
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64u * 8u) {
+      uint32_t r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t i = i0 + 64u * u + lane;
+        r[u] = i < hi ? fb.parent[i] : 0xFFFFFFFFu;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const uint32_t i = i0 + 64u * u + lane;
+        const bool sel = r[u] != 0xFFFFFFFFu && part_of(r[u]) == part;
+        const unsigned long long b = __ballot(sel);
+        if (sel && have + lanes_below(b) < P) stage[have + lanes_below(b)] = (uint16_t)i;
+        have += (uint32_t)__popcll(b);
+      }
+    }
+    if (lane == 0) L.wsum[w] = have;
+    __syncthreads();
+    const uint32_t h0 = L.wsum[0], h1 = L.wsum[1], h2 = L.wsum[2], h3 = L.wsum[3];
+    m = h0 + h1 + h2 + h3;
+    if (m > P || h0 > P || h1 > P || h2 > P || h3 > P) {     // a cluster (or a collision of clusters) beyond one workgroup
+      if (tid == 0) cnt->fallback = 1u;
+      return;
+    }
+    const uint32_t base = (w > 0 ? h0 : 0u) + (w > 1 ? h1 : 0u) + (w > 2 ? h2 : 0u);
+    for (uint32_t j = lane; j < have; j += 64) L.mine[base + j] = stage[j];
     __syncthreads();
   }
-  // ---- G3: sort 2 = (cluster, 0.2 m voxel z|y|x, point index): voxel order first, then stable by cluster ----
+  if (m == 0) return;
+  // points and local clusters: a point's seed is a point of the same partition, found by binary search in `mine`
+  uint32_t ncl;
+  {
+    uint32_t run = 0;
+    for (uint32_t e0 = 0; e0 < m; e0 += 256) {
+      const uint32_t e = e0 + tid;
+      uint32_t isr = 0;
+      if (e < m) {
+        const uint32_t i = L.mine[e];
+        const float4 p = fb.pts[i];
+        L.px[e] = p.x; L.py[e] = p.y; L.pz[e] = p.z;
+        const uint32_t r = fb.parent[i];
+        kf[e] = r;
+        isr = r == i ? 1u : 0u;
+      }
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan<4>(isr, L.wsum, &tot);
+      if (isr) { L.lcid[e] = (uint16_t)(run + ex); L.gci[run + ex] = L.mine[e]; }
+      run += tot;
+    }
+    ncl = run;
+    __syncthreads();
+    for (uint32_t e = tid; e < m; e += 256) {
+      const uint32_t r = kf[e];
+      uint32_t a = 0, b = m;                                  // first position with mine[pos] >= r
+      while (a < b) {
+        const uint32_t mid = (a + b) >> 1;
+        if ((uint32_t)L.mine[mid] < r) a = mid + 1; else b = mid;
+      }
+      kc[e] = L.lcid[a];                                       // (seeds read their own entry)
+      pc[e] = (uint16_t)e;
+    }
+    __syncthreads();
+    for (uint32_t e = tid; e < m; e += 256) L.lcid[e] = (uint16_t)kc[e];
+    __syncthreads();
+  }
+  MKF_STAMP(1);
+  // ---- P1: sort 1 = clusters in seed order, their points in index order (stable by cluster) ----
+  const int cbits = bits_for((int)ncl - 1);
+  lds_radix_sort(m, cbits, kc, pc, kf, pf, L.rk, L.hist, L.wsum);
+  for (uint32_t j = tid; j < m; j += 256)
+    if (j == 0u || kc[j - 1] != kc[j]) L.start[kc[j]] = (uint16_t)j;
+  if (tid == 0) L.start[ncl] = (uint16_t)m;
+  __syncthreads();
+  MKF_STAMP(2);
+  // ---- P2: per cluster centroid (floats added in index order, / size), min size, "centre attached to the ground"
+  //      (k_mk_cluster_stage1; :343-368) ----
+  uint32_t kept = 0;
+  for (uint32_t ci = tid; ci < ncl; ci += 256) {
+    const uint32_t b = L.start[ci], e = L.start[ci + 1], gi = L.gci[ci];
+    float cx = 0.f, cy = 0.f, cz = 0.f;
+    for (uint32_t j = b; j < e; ++j) {
+      const uint32_t q = pc[j];
+      cx += L.px[q]; cy += L.py[q]; cz += L.pz[q];
+    }
+    const float sz = (float)(e - b);
+    cx /= sz; cy /= sz; cz /= sz;
+    c.size[gi] = e - b;
+    c.centroid[gi] = make_float4(cx, cy, cz, 0.f);
+    bool ok = (int)(e - b) >= k.min_cluster;
+    if (ok) ++kept;
+    if (ok && grid_radius_count(ground, cx, cy, cz, 0.05f + 1e-4f, static_cast<float>(0.05 * 0.05), 1) > 0) ok = false;
+    L.state[ci] = ok ? 1u : 0u;
+  }
+  __syncthreads();
+  MKF_STAMP(3);
+  // ---- P3: sort 2 = (cluster, 0.2 m voxel z|y|x, point index): voxel order first, then stable by cluster ----
   int bx, by, bz, mn[3], mx[3];
   {
     const float inv = 1.0f / 0.2f;
     mn[0] = mn[1] = mn[2] = 0x7FFFFFFF; mx[0] = mx[1] = mx[2] = (int)0x80000000;
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      const uint32_t i = fpos<E>(s_);
-      if (i < n) {
-        const float4 p = fb.pts[i];
-        const int vx = (int)floorf(p.x * inv), vy = (int)floorf(p.y * inv), vz = (int)floorf(p.z * inv);
-        mn[0] = min(mn[0], vx); mx[0] = max(mx[0], vx);
-        mn[1] = min(mn[1], vy); mx[1] = max(mx[1], vy);
-        mn[2] = min(mn[2], vz); mx[2] = max(mx[2], vz);
-      }
+    for (uint32_t e = tid; e < m; e += 256) {
+      const int vx = (int)floorf(L.px[e] * inv), vy = (int)floorf(L.py[e] * inv), vz = (int)floorf(L.pz[e] * inv);
+      mn[0] = min(mn[0], vx); mx[0] = max(mx[0], vx);
+      mn[1] = min(mn[1], vy); mx[1] = max(mx[1], vy);
+      mn[2] = min(mn[2], vz); mx[2] = max(mx[2], vz);
     }
-    block_minmax3(mn, mx, red);
+    block_minmax3(mn, mx, L.red);
     // (differences in 64 bits: points may be anywhere; a range that does not fit falls back to the general route)
     const long long rx = (long long)mx[0] - mn[0], ry = (long long)mx[1] - mn[1], rz = (long long)mx[2] - mn[2];
     if (rx >= (1ll << 27) || ry >= (1ll << 27) || rz >= (1ll << 27)) { if (tid == 0) cnt->fallback = 1u; return; }
     bx = bits_for((int)rx); by = bits_for((int)ry); bz = bits_for((int)rz);
     if (bx + by + bz > kFuseKeyBits) { if (tid == 0) cnt->fallback = 1u; return; }
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      const uint32_t i = fpos<E>(s_);
-      key[s_] = 0xFFFFFFFFu; pay[s_] = 0u;
-      if (i < n) {
-        const float4 p = fb.pts[i];
-        key[s_] = ((uint32_t)((int)floorf(p.z * inv) - mn[2]) << (bx + by)) | ((uint32_t)((int)floorf(p.y * inv) - mn[1]) << bx) |
-                  (uint32_t)((int)floorf(p.x * inv) - mn[0]);
-        pay[s_] = i;
-      }
+    for (uint32_t e = tid; e < m; e += 256) {
+      kc[e] = ((uint32_t)((int)floorf(L.pz[e] * inv) - mn[2]) << (bx + by)) | ((uint32_t)((int)floorf(L.py[e] * inv) - mn[1]) << bx) |
+              (uint32_t)((int)floorf(L.px[e] * inv) - mn[0]);
+      pc[e] = (uint16_t)e;
     }
+    __syncthreads();
+    lds_radix_sort(m, bx + by + bz, kc, pc, kf, pf, L.rk, L.hist, L.wsum);
+    for (uint32_t j = tid; j < m; j += 256) kc[j] = L.lcid[pc[j]];                         // re-key by cluster
+    __syncthreads();
+    lds_radix_sort(m, cbits, kc, pc, kf, pf, L.rk, L.hist, L.wsum);
+    for (uint32_t j = tid; j < m; j += 256) {                                               // voxel key by sorted position
+      const uint32_t e = pc[j];
+      kf[j] = ((uint32_t)((int)floorf(L.pz[e] * inv) - mn[2]) << (bx + by)) | ((uint32_t)((int)floorf(L.py[e] * inv) - mn[1]) << bx) |
+              (uint32_t)((int)floorf(L.px[e] * inv) - mn[0]);
+    }
+    __syncthreads();
   }
-  for (int sh = 0; sh < bx + by + bz; sh += 7) radix_pass<E>(key, pay, sh, hist, xk, xp, wsum);
-#pragma unroll
-  for (int s_ = 0; s_ < E; ++s_) key[s_] = key[s_] == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)cid[pay[s_]];
-  radix_pass<E>(key, pay, 0, hist, xk, xp, wsum);
-  if (nc > 128u) radix_pass<E>(key, pay, 7, hist, xk, xp, wsum);
+  MKF_STAMP(4);
+  // ---- P4: 0.2 m VoxelGrid of every cluster that passed P2: one lane per voxel adds its points in order (:370-374) ----
+  const uint32_t ng2 = lds_group_index(m, kc, kf, L.state, false, L.rk, L.wsum);
+  if (tid == 0) L.misc[0] = ng2 ? atomicAdd(&cnt->n_groups2, ng2) : 0u;
   __syncthreads();
-  // ---- G4: 0.2 m VoxelGrid of every cluster that passed G2: one lane per voxel adds its points in order ----
-  uint32_t ng2;
-  {
-    const float inv = 1.0f / 0.2f;
-    uint32_t gex[E], fl = 0u;
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      const uint32_t j = fpos<E>(s_);
-      uint32_t vox = 0xFFFFFFFFu;
-      if (j < n) {
-        const float4 p = fb.pts[pay[s_]];
-        vox = ((uint32_t)((int)floorf(p.z * inv) - mn[2]) << (bx + by)) | ((uint32_t)((int)floorf(p.y * inv) - mn[1]) << bx) |
-              (uint32_t)((int)floorf(p.x * inv) - mn[0]);
-      }
-      xk[j] = vox;
+  const uint32_t ds_base = L.misc[0];
+  for (uint32_t j = tid; j < m; j += 256) {
+    if (L.rk[j + 1] == L.rk[j]) continue;                       // not a group start
+    const uint32_t cj = kc[j], vox = kf[j];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    uint32_t e = j;
+    for (; e < m && kf[e] == vox && kc[e] == cj; ++e) {
+      const uint32_t q = pc[e];
+      sx += L.px[q]; sy += L.py[q]; sz += L.pz[q];
     }
-    __syncthreads();
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      const uint32_t j = fpos<E>(s_);
-      if (j < n && state[key[s_]] != 0u) {
-        const bool first = j == 0u || (uint32_t)cid[xp[j - 1]] != key[s_] || xk[j - 1] != xk[j];
-        if (first) fl |= 1u << s_;
-      }
-    }
-    pos_excl_scan<E>(fl, gex, wsum, &ng2);
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      if (!((fl >> s_) & 1u)) continue;
-      const uint32_t j = fpos<E>(s_), cj = key[s_], vox = xk[j];
-      float sx = 0.f, sy = 0.f, sz = 0.f;
-      uint32_t e = j;
-      for (; e < n && xk[e] == vox && (uint32_t)cid[xp[e]] == cj; ++e) {
-        const float4 p = fb.pts[xp[e]];
-        sx += p.x; sy += p.y; sz += p.z;
-      }
-      const float cntf = (float)(e - j);
-      fb.ds[gex[s_]] = make_float4(sx / cntf, sy / cntf, sz / cntf, __int_as_float((int)cj));
-      atomicAdd(&c.ds_count[cj], 1u);
-    }
-    if (tid == 0) cnt->n_groups2 = ng2;
-    __threadfence();
-    __syncthreads();
+    const float cntf = (float)(e - j);
+    fb.ds[ds_base + L.rk[j]] = make_float4(sx / cntf, sy / cntf, sz / cntf, __int_as_float((int)cj));
   }
-  // ---- G5: "is it part of the static map", voxel key, in the sensor's view (k_mk_cluster_stage2) ----
-  for (uint32_t ci = tid; ci < nc; ci += kFuseThreads) {
-    if (state[ci] != 1u) continue;
-    const float4 cen = c.centroid[ci];
-    const size_t nds = ld_agent(&c.ds_count[ci]);
+  __threadfence();
+  __syncthreads();
+  MKF_STAMP(5);
+  // ---- P5: "is it part of the static map", voxel key, in the sensor's view (k_mk_cluster_stage2; :375-430) ----
+  for (uint32_t ci = tid; ci < ncl; ci += 256) {
+    if (L.state[ci] != 1u) continue;
+    const uint32_t gi = L.gci[ci];
+    const float4 cen = c.centroid[gi];
+    const size_t nds = (size_t)(L.rk[L.start[ci + 1]] - L.rk[L.start[ci]]);
     size_t hit = 0;
     if (k.ignore_ratio <= 0.999) {
+      // the loop searches with the CENTROID for every downsampled point (:380): all hit or none do
       const bool near = n_map > 0 && grid_radius_count(map, cen.x, cen.y, cen.z, 0.1f + 1e-4f, static_cast<float>(0.1 * 0.1), 1) > 0;
       if (near)
         for (size_t a = 0; a < nds; ++a) {
@@ -573,217 +625,210 @@ __device__ __forceinline__ void fuse_groups(const MarkParams& k, const FuseBufs&
           if (hit > nds * k.ignore_ratio) break;
         }
     }
-    if (!(hit <= nds * k.ignore_ratio)) { state[ci] = 0u; continue; }
+    if (!(hit <= nds * k.ignore_ratio)) { L.state[ci] = 0u; continue; }
     const int vx = (int)(cen.x / k.res), vy = (int)(cen.y / k.res), vz = (int)(cen.z / k.hres);
-    c.vkey[3 * ci + 0] = vx; c.vkey[3 * ci + 1] = vy; c.vkey[3 * ci + 2] = vz;
+    c.vkey[3 * gi + 0] = vx; c.vkey[3 * gi + 1] = vy; c.vkey[3 * gi + 2] = vz;
     const float px = (float)(vx * k.res), py = (float)(vy * k.res), pz = (float)(vz * k.hres);
-    state[ci] = in_lidar_observation(k, px, py, pz) ? 2u : 0u;
+    L.state[ci] = in_lidar_observation(k, px, py, pz) ? 2u : 0u;
   }
   __syncthreads();
-  // ---- G6: sort 3 = (cluster, 0.1 m voxel of the projected voxel centroid, order of G4) over accepted clusters ----
+  MKF_STAMP(6);
+  // ---- P6: sort 3 = (cluster, 0.1 m voxel of the projected voxel centroid, order of P4) over accepted clusters
+  //      (cluster_marking.cpp:54-64).  The projected points replace the partition's points in LDS. ----
+  uint32_t m3;
   {
+    uint32_t run = 0;
+    for (uint32_t g0 = 0; g0 < ng2; g0 += 256) {
+      const uint32_t g = g0 + tid;
+      uint32_t on = 0;
+      float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g < ng2) {
+        d = fb.ds[ds_base + g];
+        on = L.state[(uint32_t)__float_as_int(d.w)] == 2u ? 1u : 0u;
+      }
+      uint32_t tot;
+      const uint32_t ex = block_excl_scan<4>(on, L.wsum, &tot);
+      if (on) {
+        const uint32_t q = run + ex;
+        float qx, qy, qz;
+        project_on_base_plane(k, d.x, d.y, d.z, &qx, &qy, &qz);
+        L.px[q] = qx; L.py[q] = qy; L.pz[q] = qz;
+        L.lcid[q] = (uint16_t)__float_as_int(d.w);
+      }
+      run += tot;
+    }
+    m3 = run;
+    __syncthreads();
+  }
+  uint32_t ng3 = 0;
+  if (m3 > 0) {
     const float inv = 1.0f / 0.1f;
     mn[0] = mn[1] = mn[2] = 0x7FFFFFFF; mx[0] = mx[1] = mx[2] = (int)0x80000000;
-    uint32_t on = 0u;
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      const uint32_t g = fpos<E>(s_);
-      if (g < ng2) {
-        const float4 d = fb.ds[g];
-        const uint32_t ci = (uint32_t)__float_as_int(d.w);
-        cid[g] = (uint16_t)ci;
-        if (state[ci] == 2u) {
-          float qx, qy, qz;
-          project_on_base_plane(k, d, &qx, &qy, &qz);
-          on |= 1u << s_;
-          const int vx = (int)floorf(qx * inv), vy = (int)floorf(qy * inv), vz = (int)floorf(qz * inv);
-          mn[0] = min(mn[0], vx); mx[0] = max(mx[0], vx);
-          mn[1] = min(mn[1], vy); mx[1] = max(mx[1], vy);
-          mn[2] = min(mn[2], vz); mx[2] = max(mx[2], vz);
-        }
-      }
+    for (uint32_t e = tid; e < m3; e += 256) {
+      const int vx = (int)floorf(L.px[e] * inv), vy = (int)floorf(L.py[e] * inv), vz = (int)floorf(L.pz[e] * inv);
+      mn[0] = min(mn[0], vx); mx[0] = max(mx[0], vx);
+      mn[1] = min(mn[1], vy); mx[1] = max(mx[1], vy);
+      mn[2] = min(mn[2], vz); mx[2] = max(mx[2], vz);
     }
-    block_minmax3(mn, mx, red);
-    bx = by = bz = 1;
-    if (mn[0] <= mx[0]) {
-      const long long rx = (long long)mx[0] - mn[0], ry = (long long)mx[1] - mn[1], rz = (long long)mx[2] - mn[2];
-      if (rx >= (1ll << 27) || ry >= (1ll << 27) || rz >= (1ll << 27)) { if (tid == 0) cnt->fallback = 1u; return; }
-      bx = bits_for((int)rx); by = bits_for((int)ry); bz = bits_for((int)rz);
-      if (bx + by + bz > kFuseKeyBits) { if (tid == 0) cnt->fallback = 1u; return; }
+    block_minmax3(mn, mx, L.red);
+    const long long rx = (long long)mx[0] - mn[0], ry = (long long)mx[1] - mn[1], rz = (long long)mx[2] - mn[2];
+    if (rx >= (1ll << 27) || ry >= (1ll << 27) || rz >= (1ll << 27)) { if (tid == 0) cnt->fallback = 1u; return; }
+    bx = bits_for((int)rx); by = bits_for((int)ry); bz = bits_for((int)rz);
+    if (bx + by + bz > kFuseKeyBits) { if (tid == 0) cnt->fallback = 1u; return; }
+    for (uint32_t e = tid; e < m3; e += 256) {
+      kc[e] = ((uint32_t)((int)floorf(L.pz[e] * inv) - mn[2]) << (bx + by)) | ((uint32_t)((int)floorf(L.py[e] * inv) - mn[1]) << bx) |
+              (uint32_t)((int)floorf(L.px[e] * inv) - mn[0]);
+      pc[e] = (uint16_t)e;
     }
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      key[s_] = 0xFFFFFFFFu;
-      pay[s_] = fpos<E>(s_) & (N - 1u);
-      if ((on >> s_) & 1u) {
-        float qx, qy, qz;
-        project_on_base_plane(k, fb.ds[pay[s_]], &qx, &qy, &qz);
-        key[s_] = ((uint32_t)((int)floorf(qz * inv) - mn[2]) << (bx + by)) | ((uint32_t)((int)floorf(qy * inv) - mn[1]) << bx) |
-                  (uint32_t)((int)floorf(qx * inv) - mn[0]);
-      }
+    __syncthreads();
+    lds_radix_sort(m3, bx + by + bz, kc, pc, kf, pf, L.rk, L.hist, L.wsum);
+    for (uint32_t j = tid; j < m3; j += 256) kc[j] = L.lcid[pc[j]];
+    __syncthreads();
+    lds_radix_sort(m3, cbits, kc, pc, kf, pf, L.rk, L.hist, L.wsum);
+    for (uint32_t j = tid; j < m3; j += 256) {
+      const uint32_t e = pc[j];
+      kf[j] = ((uint32_t)((int)floorf(L.pz[e] * inv) - mn[2]) << (bx + by)) | ((uint32_t)((int)floorf(L.py[e] * inv) - mn[1]) << bx) |
+              (uint32_t)((int)floorf(L.px[e] * inv) - mn[0]);
     }
+    __syncthreads();
+    ng3 = lds_group_index(m3, kc, kf, L.state, true, L.rk, L.wsum);
   }
-  for (int sh = 0; sh < bx + by + bz; sh += 7) radix_pass<E>(key, pay, sh, hist, xk, xp, wsum);
-#pragma unroll
-  for (int s_ = 0; s_ < E; ++s_) key[s_] = key[s_] == 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)cid[pay[s_]];
-  radix_pass<E>(key, pay, 0, hist, xk, xp, wsum);
-  if (nc > 128u) radix_pass<E>(key, pay, 7, hist, xk, xp, wsum);
+  MKF_STAMP(7);
+  // ---- P7: 0.1 m VoxelGrid of the projected points -> generator points; first / count per cluster ----
+  if (tid == 0) L.misc[1] = ng3 ? atomicAdd(&cnt->n_groups3, ng3) : 0u;
   __syncthreads();
-  // ---- G7: 0.1 m VoxelGrid of the projected points -> generator points ----
-  {
-    const float inv = 1.0f / 0.1f;
-    uint32_t gex[E], fl = 0u, ng3;
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      const uint32_t j = fpos<E>(s_);
-      uint32_t vox = 0xFFFFFFFFu;
-      if (key[s_] != 0xFFFFFFFFu) {
-        float qx, qy, qz;
-        project_on_base_plane(k, fb.ds[pay[s_]], &qx, &qy, &qz);
-        vox = ((uint32_t)((int)floorf(qz * inv) - mn[2]) << (bx + by)) | ((uint32_t)((int)floorf(qy * inv) - mn[1]) << bx) |
-              (uint32_t)((int)floorf(qx * inv) - mn[0]);
-      }
-      xk[j] = vox;
+  const uint32_t gen_base = L.misc[1];
+  for (uint32_t j = tid; j < m3; j += 256) {
+    const uint32_t cj = kc[j];
+    if (j == 0u || kc[j - 1] != cj) L.start[cj] = L.rk[j];       // (start: now the cluster's first generator point)
+    if (L.rk[j + 1] == L.rk[j]) continue;
+    const uint32_t vox = kf[j];
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    uint32_t e = j;
+    for (; e < m3 && kf[e] == vox && kc[e] == cj; ++e) {
+      const uint32_t q = pc[e];
+      sx += L.px[q]; sy += L.py[q]; sz += L.pz[q];
     }
-    __syncthreads();
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      const uint32_t j = fpos<E>(s_);
-      if (key[s_] != 0xFFFFFFFFu) {
-        const bool first = j == 0u || (uint32_t)cid[xp[j - 1]] != key[s_] || xk[j - 1] != xk[j];
-        if (first) fl |= 1u << s_;
-      }
-    }
-    pos_excl_scan<E>(fl, gex, wsum, &ng3);
-#pragma unroll
-    for (int s_ = 0; s_ < E; ++s_) {
-      if (!((fl >> s_) & 1u)) continue;
-      const uint32_t j = fpos<E>(s_), cj = key[s_], vox = xk[j];
-      float sx = 0.f, sy = 0.f, sz = 0.f;
-      uint32_t e = j;
-      for (; e < N && xk[e] == vox && (uint32_t)cid[xp[e]] == cj; ++e) {     // (sentinels hold vox = ~0: never equal)
-        float qx, qy, qz;
-        project_on_base_plane(k, fb.ds[xp[e]], &qx, &qy, &qz);
-        sx += qx; sy += qy; sz += qz;
-      }
-      const float cntf = (float)(e - j);
-      const uint32_t h = gex[s_];
-      fb.gen[h] = make_float4(sx / cntf, sy / cntf, sz / cntf, __int_as_float((int)cj));
-      atomicAdd(&c.gen_count[cj], 1u);
-      atomicMin(&c.gen_first[cj], h);
-    }
-    if (tid == 0) cnt->n_groups3 = ng3;
-    __threadfence();
-    __syncthreads();
+    const float cntf = (float)(e - j);
+    fb.gen[gen_base + L.rk[j]] = make_float4(sx / cntf, sy / cntf, sz / cntf, __int_as_float((int)L.gci[cj]));
   }
-  // ---- G8: Marking::addPCPtr: slot of every accepted cluster (k_mk_slots), then the keeper's pool range (k_mk_commit) ----
-  {
-    uint32_t my_slot[E];
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-      const uint32_t ci = (uint32_t)q * kFuseThreads + tid;
-      my_slot[q] = 0xFFFFFFFFu;
-      if (ci >= nc) continue;
-      fb.pool_ofs[ci] = 0xFFFFFFFFu;
-      c.state[ci] = state[ci];
-      if (state[ci] != 2u) continue;
-      const unsigned long long vk = voxel_key(c.vkey[3 * ci], c.vkey[3 * ci + 1], c.vkey[3 * ci + 2]);
+  __syncthreads();
+  for (uint32_t j = tid; j < m3; j += 256) {
+    const uint32_t cj = kc[j];
+    if (j + 1 == m3 || kc[j + 1] != cj) {                       // last element of the cluster: rk[j + 1] = groups up to and including it
+      const uint32_t gi = L.gci[cj];
+      c.gen_first[gi] = gen_base + L.start[cj];
+      c.gen_count[gi] = (uint32_t)L.rk[j + 1] - (uint32_t)L.start[cj];
+    }
+  }
+  MKF_STAMP(8);
+  // ---- P8: Marking::addPCPtr, slot part (k_mk_slots): marking_[x][y][z] is created or found; the claim with the
+  //      highest priority (smallest cluster, then latest seed) keeps the voxel -- decided in the next launch ----
+  uint32_t marked = 0, dup = 0, newk = 0;
+  for (uint32_t ci = tid; ci < ncl; ci += 256) {
+    const uint32_t gi = L.gci[ci];
+    uint32_t st = L.state[ci];
+    if (st == 2u) {
+      const unsigned long long vk = voxel_key(c.vkey[3 * gi], c.vkey[3 * gi + 1], c.vkey[3 * gi + 2]);
       uint32_t slot = mk_hash(vk) & k.table_mask;
       bool found = false;
       for (uint32_t probe = 0; probe <= k.table_mask; ++probe) {
         const unsigned long long prev = atomicCAS(&s.keys[slot], 0ull, vk);
-        if (prev == 0ull) atomicAdd(&cnt->n_new_keys, 1u);
+        if (prev == 0ull) ++newk;
         if (prev == 0ull || prev == vk) { found = true; break; }
         slot = (slot + 1) & k.table_mask;
       }
-      if (!found) { atomicOr(&cnt->overflow, 1u); state[ci] = 3u; c.state[ci] = 3u; continue; }
-      c.slot[ci] = slot;
-      my_slot[q] = slot;
-      const unsigned long long pr = ((unsigned long long)((1u << 20) - min(c.size[ci], (1u << 20) - 1u)) << 20) | (unsigned long long)(ci + 1u);
-      if (atomicMax(&s.owner[slot], pr) != 0ull) atomicAdd(&cnt->n_dup, 1u);
-      atomicAdd(&cnt->n_marked, 1u);
+      if (!found) { atomicOr(&cnt->overflow, 1u); st = 3u; }   // store full: the cluster still updates the dGraph
+      else {
+        c.slot[gi] = slot;
+        const unsigned long long pr = ((unsigned long long)((1u << 20) - min(c.size[gi], (1u << 20) - 1u)) << 20) | (unsigned long long)(gi + 1u);
+        if (atomicMax(&s.owner[slot], pr) != 0ull) ++dup;
+        ++marked;
+      }
     }
-    __threadfence();
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < E; ++q) {
-      const uint32_t ci = (uint32_t)q * kFuseThreads + tid, slot = my_slot[q];
-      if (slot == 0xFFFFFFFFu) continue;
-      const unsigned long long pr = ((unsigned long long)((1u << 20) - min(c.size[ci], (1u << 20) - 1u)) << 20) | (unsigned long long)(ci + 1u);
-      if (ld_agent(&s.owner[slot]) != pr) continue;
-      const uint32_t ng = ld_agent(&c.gen_count[ci]);
-      const uint32_t ofs = atomicAdd(&cnt->pool_used, ng);
-      if (ofs + ng > k.pool_cap) { atomicOr(&cnt->overflow, 2u); s.alive[slot] = 0; s.pts_n[slot] = 0; continue; }
-      fb.pool_ofs[ci] = ofs;
-      s.pts_ofs[slot] = ofs;
-      s.pts_n[slot] = ng;
-      s.alive[slot] = 1;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < E; ++q)
-      if (my_slot[q] != 0xFFFFFFFFu) s.owner[my_slot[q]] = 0ull;       // next update starts with no owners
+    c.state[gi] = st;
   }
+  // the partition's share of the update's counters
+  {
+    uint32_t t0, t1, t2, t3;
+    (void)block_excl_scan<4>(kept, L.wsum, &t0);
+    (void)block_excl_scan<4>(marked, L.wsum, &t1);
+    (void)block_excl_scan<4>(dup, L.wsum, &t2);
+    (void)block_excl_scan<4>(newk, L.wsum, &t3);
+    if (tid == 0) {
+      if (t0) atomicAdd(&cnt->n_clusters_kept, t0);
+      if (t1) atomicAdd(&cnt->n_marked, t1);
+      if (t2) atomicAdd(&cnt->n_dup, t2);
+      if (t3) atomicAdd(&cnt->n_new_keys, t3);
+    }
+  }
+  MKF_STAMP(9);
 }
 
-template <int E>
-__global__ __launch_bounds__(kFuseThreads) void k_mkf_unmark_groups(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
-                                                                    PointGrid map, uint32_t n_map, MarkCounters* __restrict__ cnt) {
+__global__ __launch_bounds__(kPartThreads) void k_mkf_groups(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
+                                                             PointGrid map, uint32_t n_map, MarkCounters* __restrict__ cnt, uint32_t n_parts) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fuse_lds[];
-  if (blockIdx.x == 0) {
-    if (k.n_obs > 5u) fuse_groups<E>(k, fb, c, s, ground, map, n_map, cnt, fuse_lds);
+  if (blockIdx.x < n_parts) {
+    fuse_partition(k, fb, c, s, ground, map, n_map, cnt, fuse_lds);
     return;
   }
   const int lane = threadIdx.x & 63;
-  const uint32_t stride = (gridDim.x - 1u) * 16u, n_removed = cnt->n_removed;
-  for (uint32_t r = (blockIdx.x - 1u) * 16u + (threadIdx.x >> 6); r < n_removed; r += stride)
+  const uint32_t stride = (gridDim.x - n_parts) * 4u, n_removed = cnt->n_removed;
+  for (uint32_t r = (blockIdx.x - n_parts) * 4u + (threadIdx.x >> 6); r < n_removed; r += stride)
     fuse_unmark_wave(k, s, ground, fb.removed_on[r], lane);
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 4: dGraph / lethal update of the new generator points (k_mk_dgraph)  |  alive list (k_mk_finish); the last
-// block to finish publishes the counters and leaves them zeroed for the next update
+// launch 5: the keeper of every claimed voxel stores its generator points (k_mk_commit)  |  dGraph / lethal update of
+// the new generator points (k_mk_dgraph); the last block to finish publishes the counters and leaves them zeroed
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mkf_dgraph_finish(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
-                                                           MarkCounters* __restrict__ cnt, uint32_t nb_dg) {
+__global__ __launch_bounds__(256) void k_mkf_commit_dgraph(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
+                                                           MarkCounters* __restrict__ cnt, uint32_t nb_commit) {
   const int lane = threadIdx.x & 63;
-  if (blockIdx.x < nb_dg) {
-    const uint32_t n_gen = cnt->n_groups3;
+  const bool fallback = cnt->fallback != 0u;
+  if (fallback) {
+    // the mark phase is redone on the general route: nothing of this attempt may reach the store
+  } else if (blockIdx.x < nb_commit) {
+    const uint32_t gi = blockIdx.x * 256 + threadIdx.x;
+    if (gi < k.n_obs && c.state[gi] == 2u) {
+      const uint32_t slot = c.slot[gi];
+      const unsigned long long pr = ((unsigned long long)((1u << 20) - min(c.size[gi], (1u << 20) - 1u)) << 20) | (unsigned long long)(gi + 1u);
+      if (s.owner[slot] == pr) {
+        const uint32_t ng = c.gen_count[gi], first = c.gen_first[gi];
+        const uint32_t ofs = atomicAdd(&cnt->pool_used, ng);
+        const uint32_t was = s.alive[slot];
+        if (ofs + ng > k.pool_cap) {
+          atomicOr(&cnt->overflow, 2u);
+          s.alive[slot] = 0; s.pts_n[slot] = 0;
+          if (was) atomicAdd(&cnt->n_revived, 0xFFFFFFFFu);
+        } else {
+          for (uint32_t i = 0; i < ng; ++i) {
+            const float4 p = fb.gen[first + i];
+            s.pool[ofs + i] = make_float4(p.x, p.y, p.z, 0.f);
+          }
+          s.pts_ofs[slot] = ofs;
+          s.pts_n[slot] = ng;
+          s.alive[slot] = 1;
+          if (!was) atomicAdd(&cnt->n_revived, 1u);
+        }
+      }
+    }
+  } else {
+    const uint32_t n_gen = cnt->n_groups3, nb_dg = gridDim.x - nb_commit;
     const float r = (float)k.inflation, r2 = static_cast<float>(k.inflation * k.inflation);
-    for (uint32_t h = blockIdx.x * 4 + (threadIdx.x >> 6); h < n_gen; h += nb_dg * 4) {
+    for (uint32_t h = (blockIdx.x - nb_commit) * 4 + (threadIdx.x >> 6); h < n_gen; h += nb_dg * 4) {
       const float4 p = fb.gen[h];
-      const uint32_t ci = (uint32_t)__float_as_int(p.w);
-      const uint32_t po = fb.pool_ofs[ci];
-      if (lane == 0 && po != 0xFFFFFFFFu) s.pool[po + (h - c.gen_first[ci])] = make_float4(p.x, p.y, p.z, 0.f);
+      // computeMinDistanceFromObstacle2GroundNodes + DynamicGraph::setValue + lethal_map_ (cluster_marking.cpp:66-123)
       ground_ball_wave(ground, p.x, p.y, p.z, r + 1e-4f, lane, [&](const float4 g) {
         if (l2_simple(g.x, g.y, g.z, p.x, p.y, p.z) < r2) {
           const int node = __float_as_int(g.w);
           const float dx = p.x - g.x, dy = p.y - g.y;
-          const float d = sqrtf(dx * dx + dy * dy);                    // z dropped on purpose (cluster_marking.cpp:86-88)
+          const float d = sqrtf(dx * dx + dy * dy);                    // z dropped on purpose (:86-88)
+          // setValue: graph_[key] = min(graph_[key], d); non-negative doubles order like their bit patterns
           atomicMin(reinterpret_cast<unsigned long long*>(s.dgraph) + node, (unsigned long long)__double_as_longlong((double)d));
           if (d <= k.inscribed) s.lethal[node] = 1;
         }
       });
-    }
-  } else {
-    __shared__ uint32_t base;
-    const uint32_t slot = (blockIdx.x - nb_dg) * 256 + threadIdx.x;
-    const bool al = slot <= k.table_mask && s.alive[slot] != 0u;
-    const unsigned long long b = __ballot(al);
-    const int w = threadIdx.x >> 6;
-    __shared__ uint32_t wc[4];
-    if (lane == 0) wc[w] = (uint32_t)__popcll(b);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t tot = wc[0] + wc[1] + wc[2] + wc[3];
-      base = tot ? atomicAdd(&cnt->n_alive, tot) : 0u;
-    }
-    __syncthreads();
-    if (al) {
-      uint32_t o = base;
-      for (int j = 0; j < w; ++j) o += wc[j];
-      o += __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-      s.alive_list[o] = slot;
     }
   }
   // ---- last block out: counters -> host-mapped record, device copy zeroed (the pool fill carries over) ----

@@ -49,6 +49,8 @@ struct MarkingState {
   uint32_t seq = 0;
   // fused route (marking_fused.hip.h)
   uint2* removed_on = nullptr;             // [table]
+  uint32_t* clear_list = nullptr;          // [table]
+  bool alive_list_stale = false;           // the fused route keeps no alive list: the general route rebuilds it first
   uint32_t* ticket = nullptr;              // [2]
   MarkCounters* host_out = nullptr;        // host-mapped (hipHostMalloc), host_out_dev = its device address
   MarkCounters* host_out_dev = nullptr;
@@ -83,7 +85,7 @@ void marking_free(MarkingState* m) {
                m->gslot, m->parent, m->keys_a, m->keys_b, m->keys1, m->vals_a, m->vals_b, m->flags, m->incl, m->cid_incl, m->ds,
                m->proj, m->gen, m->ds_first, m->pool_ofs, m->compact_sizes, m->compact_ofs, m->cl.start, m->cl.size, m->cl.centroid,
                m->cl.state, m->cl.ds_count, m->cl.gen_first, m->cl.gen_count, m->cl.slot, m->cl.vkey, m->counters, m->n_groups,
-               m->temp, m->removed_on, m->ticket};
+               m->temp, m->removed_on, m->ticket, m->clear_list};
   for (void* q : p)
     if (q) (void)hipFree(q);
   if (m->host_out) (void)hipHostFree(m->host_out);
@@ -216,8 +218,8 @@ int marking_fix_ties(dddmr_rollout_ctx* ctx, MarkingState* m, const MarkParams& 
   struct Item { uint32_t size, ci; };
   std::vector<Item> order;
   order.reserve(nc);
-  for (uint32_t ci = 0; ci < nc; ++ci)
-    if ((int)size[ci] >= m->cfg.euclidean_cluster_extraction_min_cluster_size) order.push_back(Item{size[ci], ci});
+  for (uint32_t ci = 0; ci < nc; ++ci)     // (size 0: a point index that seeds no cluster, fused route)
+    if (size[ci] > 0 && (int)size[ci] >= m->cfg.euclidean_cluster_extraction_min_cluster_size) order.push_back(Item{size[ci], ci});
   std::sort(order.rbegin(), order.rend(), [](const Item& a, const Item& b) { return a.size < b.size; });
   // per contested voxel: the accepted cluster the reference processes last, against the one the device kept
   struct Keep { uint32_t ref_ci, dev_ci, dev_size, claims; };
@@ -241,9 +243,13 @@ int marking_fix_ties(dddmr_rollout_ctx* ctx, MarkingState* m, const MarkParams& 
   HIPCHK(ctx, hipMemcpyAsync(fix_dev, fix.data(), fix.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(k_mk_fix_owner, dim3((unsigned)((fix.size() + 3) / 4)), dim3(256), 0, st, k, (uint32_t)fix.size(), fix_dev,
                      m->gen, m->cl, s, m->counters);
-  HIPCHK(ctx, hipMemcpyAsync(&out, m->counters, sizeof(out), hipMemcpyDeviceToHost, st));
+  MarkCounters after{};                                // (on the fused route the device copy holds only what k_mk_fix_owner touches)
+  HIPCHK(ctx, hipMemcpyAsync(&after, m->counters, sizeof(after), hipMemcpyDeviceToHost, st));
   HIPCHK(ctx, hipStreamSynchronize(st));               // (also keeps `fix` alive until the copy has run)
   HIPCHK(ctx, hipGetLastError());
+  out.pool_used = after.pool_used;
+  out.overflow |= after.overflow;
+  if (after.overflow) m->counters_clean = false;
   m->pool_used_host = out.pool_used;
   return DDDMR_OK;
 }
@@ -353,18 +359,14 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     HIPCHK(ctx, hipMalloc(&m->counters, sizeof(MarkCounters)));
     HIPCHK(ctx, hipMalloc(&m->n_groups, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&m->removed_on, (size_t)table * sizeof(uint2)));
+    HIPCHK(ctx, hipMalloc(&m->clear_list, (size_t)table * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&m->ticket, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(m->ticket, 0, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(m->counters, 0, sizeof(MarkCounters)));
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->host_out), sizeof(MarkCounters), hipHostMallocMapped));
     HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&m->host_out_dev), m->host_out, 0));
     if (const char* e = std::getenv("DDDMR_MARKING_ROUTE")) m->route = std::strcmp(e, "general") == 0 ? 0 : (std::strcmp(e, "fused") == 0 ? 1 : -1);
-    {
-      const void* fk[] = {reinterpret_cast<const void*>(k_mkf_unmark_groups<4>), reinterpret_cast<const void*>(k_mkf_unmark_groups<8>),
-                          reinterpret_cast<const void*>(k_mkf_unmark_groups<16>)};
-      const size_t fl[] = {fuse_groups_lds_bytes<4>(), fuse_groups_lds_bytes<8>(), fuse_groups_lds_bytes<16>()};
-      for (int i = 0; i < 3; ++i) HIPCHK(ctx, hipFuncSetAttribute(fk[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl[i]));
-    }
+    HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mkf_groups), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLdsBytes));
     HIPCHK(ctx, hipEventCreate(&m->e0));
     HIPCHK(ctx, hipEventCreate(&m->e1));
     HIPCHK(ctx, hipEventCreate(&m->e2));
@@ -406,6 +408,7 @@ int marking_reset_locked(dddmr_rollout_ctx* ctx) {
   m->n_alive_host = 0;
   m->keys_used_host = 0;
   m->counters_clean = false;
+  m->alive_list_stale = false;               // (nothing alive: the empty list is right)
   // (pcl_msg_gbl_ is untouched by resetdGraph: the previous observation stays)
   return DDDMR_OK;
 }
@@ -534,6 +537,11 @@ int update_general(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f
   if (timed) HIPCHK(ctx, hipEventRecord(m->e0, st));
   int rc = store_maintenance(ctx, m, st);
   if (rc != DDDMR_OK) return rc;
+  if (m->alive_list_stale) {                 // the last update ran fused: what selfClear walks has to be listed first
+    MK_LAUNCH(m, k_mk_finish, dim3((m->table + 255) / 256), dim3(256), 0, st, k, s, m->counters);
+    HIPCHK(ctx, hipMemsetAsync(&m->counters->n_alive, 0, sizeof(uint32_t), st));
+    m->alive_list_stale = false;
+  }
   // ---- selfClear against the previous observation ----
   const PointGrid empty_grid = m->obs[0].g;
   const PointGrid& prev_grid = m->prev >= 0 ? m->obs[m->prev].g : empty_grid;
@@ -556,7 +564,7 @@ int update_general(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f
   return DDDMR_OK;
 }
 
-// one update on the fused route: four launches, no copies (marking_fused.hip.h)
+// one update on the fused route: five launches, no copies (marking_fused.hip.h)
 int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, const float4* obs, uint32_t n_obs, bool timed,
                  MarkCounters& out) {
   hipStream_t st = ctx->stream;
@@ -582,50 +590,51 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
     obs_grid_shape(m, f, std::min(gb.cap_cells, kFuseMaxCells), gb.g, lo, hi);
     gb.g.n = n_obs;
   }
-  FuseBufs fb{obs, m->parent, m->proj, m->ds, m->gen, m->pool_ofs, m->removed_on, m->ticket, m->host_out_dev};
+  FuseBufs fb{obs, m->parent, m->ds, m->gen, m->clear_list, m->removed_on, m->ticket, m->host_out_dev};
   const uint32_t n_alive = m->n_alive_host;
-  // 1: observation grid | window + FOV test
-  if (mark || n_alive)
-    MK_LAUNCH(m, k_mkf_pre, dim3(1 + (n_alive + kFuseThreads - 1) / kFuseThreads), dim3(kFuseThreads), 0, st, k, s, gb.g, obs, m->parent,
-              m->counters);
+  // 1: observation grid | every store slot: window + FOV test -> ray-test list
+  MK_LAUNCH(m, k_mkf_pre, dim3(1 + (m->table + 1023) / 1024), dim3(1024), 0, st, k, s, gb.g, fb, m->counters);
   // 2: ray tests | union-find
   const uint32_t nb_clear = (n_alive + 3) / 4, nb_cc = mark ? (n_obs * 4 + 255) / 256 : 0;
   if (nb_clear + nb_cc)
-    MK_LAUNCH(m, k_mkf_clear_cc, dim3(nb_clear + nb_cc), dim3(256), 0, st, k, s, prev_grid, gb.g, obs, m->parent, m->removed_on, m->counters,
-              nb_clear);
+    MK_LAUNCH(m, k_mkf_clear_cc, dim3(nb_clear + nb_cc), dim3(256), 0, st, k, s, prev_grid, gb.g, fb, m->counters, nb_clear);
   if (timed) HIPCHK(ctx, hipEventRecord(m->e1, st));
-  // 3: the grouping chain in one workgroup | removePCPtr of the cleared markings
-  const uint32_t nb_un = n_alive ? std::min<uint32_t>(255u, (n_alive + 63) / 64) : 0;
-  if (mark || nb_un) {
-    const dim3 g3(1 + nb_un), b3(kFuseThreads);
-    if (n_obs <= 4096)
-      MK_LAUNCH(m, k_mkf_unmark_groups<4>, g3, b3, fuse_groups_lds_bytes<4>(), st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map, m->counters);
-    else if (n_obs <= 8192)
-      MK_LAUNCH(m, k_mkf_unmark_groups<8>, g3, b3, fuse_groups_lds_bytes<8>(), st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map, m->counters);
-    else
-      MK_LAUNCH(m, k_mkf_unmark_groups<16>, g3, b3, fuse_groups_lds_bytes<16>(), st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map, m->counters);
-  }
-  // 4: dGraph of the new generator points | alive list; the last block publishes the counters
-  const uint32_t nb_dg = mark ? std::min<uint32_t>((n_obs + 3) / 4, 2048u) : 0, nb_fin = (m->table + 255) / 256;
-  MK_LAUNCH(m, k_mkf_dgraph_finish, dim3(nb_dg + nb_fin), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters, nb_dg);
+  // 3: seeds
+  if (mark) MK_LAUNCH(m, k_mkf_roots, dim3((n_obs + 255) / 256), dim3(256), 0, st, n_obs, m->parent, m->cl);
+  // 4: 64 partitions of the clusters | removePCPtr of the cleared markings
+  const uint32_t n_parts = mark ? (uint32_t)kFuseParts : 0u;
+  const uint32_t nb_un = n_alive ? std::min<uint32_t>(192u, (n_alive + 15) / 16) : 0;
+  if (n_parts + nb_un)
+    MK_LAUNCH(m, k_mkf_groups, dim3(n_parts + nb_un), dim3(kPartThreads), kPartLdsBytes, st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map,
+              m->counters, n_parts);
+  // 5: keepers -> pool | dGraph of the new generator points; the last block publishes the counters
+  const uint32_t nb_commit = mark ? (n_obs + 255) / 256 : 0, nb_dg = mark ? std::min<uint32_t>((n_obs + 3) / 4, 2048u) : 1u;
+  MK_LAUNCH(m, k_mkf_commit_dgraph, dim3(nb_commit + nb_dg), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters, nb_commit);
   if (timed) HIPCHK(ctx, hipEventRecord(m->e2, st));
   HIPCHK(ctx, hipStreamSynchronize(st));
   HIPCHK(ctx, hipGetLastError());
   out = *m->host_out;
   m->counters_clean = true;
+  m->alive_list_stale = true;
   ++m->updates_fused;
+  out.n_alive = n_alive - out.n_cleared + out.n_revived;
+  out.n_clusters = n_obs;                                                        // extent of the per-cluster records (named by seed index)
   if (mark && !out.fallback) {
     m->prev = cur;                                                               // pcl_msg_gbl_ of this selfMark
     m->n_prev = n_obs;
   }
   if (!out.fallback) return DDDMR_OK;
-  // The observation's voxel range did not fit the 28-bit sort keys (points hundreds of metres apart: only a cloud
-  // handed over with set_cloud can do that): the clear phase stands, the mark phase is redone on the general route.
+  // A cluster beyond one partition workgroup, or voxel ranges beyond the 28-bit sort keys (points hundreds of metres
+  // apart: only a cloud handed over with set_cloud can do that): the clear phase stands, nothing of the mark phase
+  // has reached the store but keys and claims, and the mark phase is redone on the general route.
   --m->updates_fused;
   m->counters_clean = false;
+  HIPCHK(ctx, hipMemsetAsync(s.owner, 0, (size_t)m->table * sizeof(unsigned long long), st));
+  MarkCounters zero{};
+  zero.pool_used = out.pool_used;
+  HIPCHK(ctx, hipMemcpyAsync(m->counters, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
   rc = mark_general(ctx, m, f, obs, n_obs, st);
   if (rc != DDDMR_OK) return rc;
-  HIPCHK(ctx, hipMemsetAsync(&m->counters->n_alive, 0, sizeof(uint32_t), st));
   MK_LAUNCH(m, k_mk_finish, dim3((m->table + 255) / 256), dim3(256), 0, st, k, s, m->counters);
   if (timed) HIPCHK(ctx, hipEventRecord(m->e2, st));
   MarkCounters g{};
@@ -633,8 +642,10 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   HIPCHK(ctx, hipStreamSynchronize(st));
   HIPCHK(ctx, hipGetLastError());
   g.n_in_window = out.n_in_window; g.n_cleared = out.n_cleared; g.n_removed = out.n_removed; g.n_rehashed = out.n_rehashed;
+  g.n_new_keys += out.n_new_keys;
   g.fallback = 1u;
   out = g;
+  m->alive_list_stale = false;
   ++m->updates_general;
   return DDDMR_OK;
 }
@@ -758,6 +769,13 @@ int dddmr_rollout_marking_route_counts(dddmr_rollout_ctx* ctx, uint32_t* updates
   if (launches_last_update) *launches_last_update = m->launches_last;
   return DDDMR_OK;
 }
+
+#ifdef DDDMR_PHASE_STAMPS
+// diagnostic build only: phase stamps of the last fused update's two single-workgroup blocks
+int dddmr_rollout_diag_mkstamps(unsigned long long* out, size_t n_words) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dddmr::g_mk_stamps), n_words * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int dddmr_rollout_marking_get_voxels(dddmr_rollout_ctx* ctx, int32_t* xyz_out, size_t capacity, size_t* n) {
   if (!ctx || !n) return DDDMR_ERR_BAD_ARG;
