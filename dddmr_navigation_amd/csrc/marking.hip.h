@@ -135,6 +135,7 @@ struct MarkCounters {         // device counters of one update (copied back for 
   uint32_t fallback;     // fused route: a partition or its voxel sort keys did not fit, the mark phase has to take the general route
   uint32_t n_clear;      // fused route: stored markings inside the window and the sensor's view (entries of the ray-test list)
   uint32_t n_revived;    // fused route: markings that went from not alive to alive in the commit
+  uint32_t n_unmark_pts; // fused route: generator points of the markings this update's selfClear removed
 };
 
 // isinLidarObservation (:682-746).  The reference builds a rotation that turns the x axis onto the viewing
@@ -221,36 +222,62 @@ __global__ __launch_bounds__(256) void k_mk_fov(MarkParams k, MarkStore s, MarkC
   s.fov_flag[w] = flag;
 }
 
-// The ray test of one stored marking by one wave.  removed_on (the fused route, marking_fused.hip.h): the pool range of
-// a removed marking is recorded with it, because that route's commit may hand the slot to a new cluster in the same
-// launch that runs removePCPtr.
+#ifdef DDDMR_PHASE_STAMPS
+__device__ unsigned long long g_mk_clear_cyc[8];   // diagnostic build: [0] rays, [1] chunks probed, cycles of [2] phase A, [3] phase B, [4] near test, [5] removal
+#define MKC_NOW() clock64()
+#define MKC_ADD(i, v) do { if (lane == 0) atomicAdd(&g_mk_clear_cyc[i], (unsigned long long)(v)); } while (0)
+#else
+#define MKC_NOW() 0ll
+#define MKC_ADD(i, v) do { (void)sizeof(v); } while (0)
+#endif
+// The ray test of one stored marking by one wave.  unmark_pts (the fused route, marking_fused.hip.h): the generator
+// points of a removed marking are copied to a flat list (that route's removePCPtr runs ground node by ground node over
+// all of them, and its commit may hand the slot to a new cluster meanwhile).
 __device__ __forceinline__ void mk_clear_wave(const MarkParams& k, const MarkStore& s, const PointGrid& prev, MarkCounters* __restrict__ cnt,
-                                              const uint32_t slot, const int lane, uint2* __restrict__ removed_on) {
+                                              const uint32_t slot, const int lane, float4* __restrict__ unmark_pts) {
   int x, y, z;
   voxel_unkey(s.keys[slot], &x, &y, &z);
   const float px = (float)(x * k.res), py = (float)(y * k.res), pz = (float)(z * k.hres);
   const bool observation_clear = !(k.n_prev > 5);
   bool blocked = false;
+  const long long mkc0 = MKC_NOW();
+  MKC_ADD(0, 1);
   if (!observation_clear) {
     // getCastingPointCloud: points every 5 cm from the sensor to the voxel, t accumulated in float
     const float dX = (float)(px - k.st[0]), dY = (float)(py - k.st[1]), dZ = (float)(pz - k.st[2]);
     float distance = sqrtf(dX * dX + dY * dY + dZ * dZ);
+    const float len = distance;                                     // metres from the sensor to the voxel
     distance = (float)(distance / 0.05);
     const float dt = 1 / distance;
     float t0 = 0.f;                                                 // t of lane 0 in this chunk of 64 ray points
     for (int chunk = 0; chunk < 4096; ++chunk) {
+      MKC_ADD(1, 1);
+      // The reference's running float sum t += dt: lane i holds the i-th partial sum.  One chain for the wave: every step
+      // each lane takes its left neighbour's value + dt (DPP wave_shr:1) and lane 0 is put back to t0, so after 63 steps
+      // lane i has been through exactly i additions, in order.
       float t = t0;
-      for (int i = 0; i < lane; ++i) t += dt;                       // the reference's running float sum
+#pragma unroll
+      for (int j = 0; j < 63; ++j) {
+        const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x138, 0xF, 0xF, false));
+        t = lane == 0 ? t0 : left + dt;
+      }
       const bool live = t <= 1.0;
       bool stop = false, hit = false;
       if (live) {
         const float ax = (float)(k.st[0] + dX * t), ay = (float)(k.st[1] + dY * t), az = (float)(k.st[2] + dZ * t);
-        const double ddx = px - ax, ddy = py - ay, ddz = pz - az;   // getDistanceBTWPoints
-        const float intensity = (float)sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
-        stop = intensity < 0.05;                                    // the last 5 cm are ignored (:563-564)
-        if (!stop) {
-          double sd = intensity / 20. + 0.01;
+        // search radius min(intensity / 20 + 0.01, 0.1), intensity = distance to the voxel: 0.1 beyond 1.8 m.  A float
+        // estimate of that distance (error < 1 mm for rays of tens of metres) settles all but the last 2 m of the ray;
+        // there the reference's double arithmetic runs.
+        const float est = len * (1.0f - t);
+        double sd = 0.1;
+        if (est < 2.0f) {
+          const double ddx = px - ax, ddy = py - ay, ddz = pz - az;   // getDistanceBTWPoints
+          const float intensity = (float)sqrt(ddx * ddx + ddy * ddy + ddz * ddz);
+          stop = intensity < 0.05;                                  // the last 5 cm are ignored (:563-564)
+          sd = intensity / 20. + 0.01;
           sd = fmin(sd, 0.1);
+        }
+        if (!stop) {
           const float r2 = static_cast<float>(sd * sd);
           hit = grid_radius_count(prev, ax, ay, az, (float)sd + 1e-4f, r2, 1) > 0;
         }
@@ -263,21 +290,31 @@ __device__ __forceinline__ void mk_clear_wave(const MarkParams& k, const MarkSto
       t0 = __shfl(t, 63, 64) + dt;
     }
   }
+  const long long mkc2 = MKC_NOW();
+  MKC_ADD(3, mkc2 - mkc0);
   if (blocked) return;                                              // the ray is blocked: keep (:582-591)
   int near = 0;
   if (!observation_clear) {
     const float r2 = static_cast<float>(k.res * k.res);
     near = grid_radius_count(prev, px, py, pz, (float)k.res + 1e-4f, r2, 2);
   }
+  const long long mkc3 = MKC_NOW();
+  MKC_ADD(4, mkc3 - mkc2);
   if (near > 1) return;                                             // still observed (:596-605)
+  uint32_t base = 0;
   if (lane == 0) {                                                  // Marking::removePCPtr
     s.alive[slot] = 0;
     s.removed_seq[slot] = k.seq;
     atomicAdd(&cnt->n_cleared, 1u);
-    const uint32_t at = atomicAdd(&cnt->n_removed, 1u);
-    s.removed_list[at] = slot;
-    if (removed_on) removed_on[at] = make_uint2(s.pts_ofs[slot], s.pts_n[slot]);
+    s.removed_list[atomicAdd(&cnt->n_removed, 1u)] = slot;
+    if (unmark_pts) base = atomicAdd(&cnt->n_unmark_pts, s.pts_n[slot]);
   }
+  if (unmark_pts) {                                                 // its generator points, for the node-by-node removePCPtr
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    const uint32_t ofs = s.pts_ofs[slot], n = s.pts_n[slot];
+    for (uint32_t i = lane; i < n; i += 64) unmark_pts[base + i] = s.pool[ofs + i];
+  }
+  MKC_ADD(5, MKC_NOW() - mkc3);
 }
 __global__ __launch_bounds__(256) void k_mk_clear(MarkParams k, MarkStore s, PointGrid prev, MarkCounters* __restrict__ cnt) {
   const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);

@@ -1,4 +1,4 @@
-// marking_fused.hip.h -- the marking / clearing update for observations of up to 16384 points in FIVE launches.
+// marking_fused.hip.h -- the marking / clearing update for observations of up to 16384 points in SIX launches.
 //
 // The general route (marking.hip.h + rocPRIM sorts, any observation size) issues ~55 launches per update, ~30 of them
 // at the 4.5-4.9 us launch floor, plus three mid-update copies: for the observation of a 16-line LiDAR the update is
@@ -7,15 +7,16 @@
 // tests, the hash insert -- runs in 64 independent 256-lane workgroups, each on the clusters whose seed point hashes
 // to it, with points, sort keys and payloads resident in LDS:
 //
-//   launch 1  k_mkf_pre             block 0: grid of the new observation, built in LDS by one workgroup
-//                                   blocks 1..: every store slot: window + field-of-view test -> list of ray tests
-//   launch 2  k_mkf_clear_cc        selfClear ray tests (a wave per listed marking)  |  Euclidean clustering (union-find)
-//   launch 3  k_mkf_roots           every point's cluster seed (root of the union-find)
-//   launch 4  k_mkf_groups          blocks 0..63: partition p = clusters with hash(seed) = p: centroids -> 0.2 m
-//                                   VoxelGrid -> static / FOV tests -> projection + 0.1 m VoxelGrid -> store slots
-//                                   blocks 64..: removePCPtr of the markings launch 2 cleared
-//   launch 5  k_mkf_commit_dgraph   keeper of every claimed voxel -> pool  |  dGraph / lethal update of the new
-//                                   generator points; the last block publishes the counters to host-mapped memory
+//   launch 1  k_mkf_pre             cell counts of the new observation's grid  |  every store slot: window + field-of-view
+//                                   test -> list of ray tests
+//   launch 2  k_mkf_grid            one workgroup: scan of the cell counts in LDS, scatter
+//   launch 3  k_mkf_clear_cc        selfClear ray tests (a wave per listed marking)  |  Euclidean clustering (union-find)
+//   launch 4  k_mkf_roots_unmark    every point's cluster seed (root of the union-find)  |  removePCPtr of the markings
+//                                   launch 3 cleared, ground node by ground node
+//   launch 5  k_mkf_groups          64 blocks, partition p = clusters with hash(seed) = p: centroids -> 0.2 m VoxelGrid
+//                                   -> static / FOV tests -> projection + 0.1 m VoxelGrid -> store slots
+//   launch 6  k_mkf_commit_dgraph   keeper of every claimed voxel -> pool  |  dGraph / lethal update, ground node by
+//                                   ground node; the last block publishes the counters to host-mapped memory
 //
 // (A first version ran the grouping chain in ONE 1024-lane workgroup with the keys in registers: 670 us at 10.5 k
 // points -- a wave64 VALU instruction occupies its SIMD for four cycles and one CU is 1/256 of the chip; the phase
@@ -34,7 +35,7 @@
 namespace dddmr {
 
 constexpr uint32_t kFuseMaxObs = 16384;      // points of an observation the fused route takes
-constexpr uint32_t kFuseMaxCells = 32768;    // cells of the observation grid (16-bit counters, two per LDS word)
+constexpr uint32_t kFuseMaxCells = 65536;    // cells of the observation grid (16-bit counters, two per LDS word: 132 KB)
 constexpr int kFuseParts = 64;               // partitions of the clusters (by hash of the seed point index)
 constexpr uint32_t kPartCap = 4096;          // points one partition workgroup takes (16 per lane)
 constexpr int kPartThreads = 256;
@@ -54,8 +55,10 @@ struct FuseBufs {
   float4* ds;              // [n] 0.2 m voxel centroids, w = cluster (scratch of a partition between its two halves)
   float4* gen;             // [n] generator points, w = cluster
   uint32_t* clear_list;    // [table] slots inside the window and the sensor's view
-  uint2* removed_on;       // [table] (pool offset, count) of the markings this update's selfClear removed
+  float4* unmark_pts;      // [pool] generator points of the markings this update's selfClear removed
   uint32_t* ticket;        // [2]
+  uint32_t* cell_count;    // [kFuseMaxCells] all zero between updates
+  unsigned long long* slot;  // [n] (rank << 32) | cell of a point in the observation grid
   MarkCounters* host_out;  // host-mapped copy of the update's counters
 };
 
@@ -65,6 +68,11 @@ __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
 __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// This wave's stores and atomics have been acknowledged (written through to the level every CU of the chip reads:
+// device-scope atomics and sc1 loads go there).  What a hand-off inside a launch needs here is exactly that plus a
+// barrier / ticket; an agent-scope fence (__threadfence) also writes the XCD's L2 back, which cost the last launch
+// 120 us when all 2090 workgroups issued one (profiles/r03_C5M_fused_kernel_stats.csv history in DESIGN.md).
+__device__ __forceinline__ void wait_own_memory_ops() { __asm__ volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
 __device__ __forceinline__ uint32_t lanes_below(unsigned long long m) {
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -101,101 +109,138 @@ __device__ __forceinline__ void project_on_base_plane(const MarkParams& k, float
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 1, block 0: uniform grid of the observation (<= 16384 points, <= 32768 cells) built by one workgroup with
-// the cell counters in LDS (16 bits each, two per word: the count pass and the scan never leave the CU)
+// launches 1 + 2: uniform grid of the observation (<= 16384 points, <= 65536 cells).  The blocks of launch 1 count 256
+// points each into the cells (device-scope atomics: the rank inside the cell comes back) and leave (cell, rank) per point;
+// launch 2, one workgroup, scans the counters in LDS (16 bits each, two per word), writes the cell starts, leaves the
+// counters zeroed for the next update and scatters the points.  (As the last-ticket block of launch 1 the scan had to
+// read the counters past its XCD's L2, one sc1 load after the other: 60 us; built in LDS by one workgroup from scratch,
+// count included: 41 us.)  The order of the points inside a cell is whatever the atomics made it: no result depends on
+// it (radius tests look at every point of a cell).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fuse_build_grid(PointGrid g, const float4* __restrict__ pts, uint32_t* __restrict__ parent,
-                                                uint32_t* cnt2 /* [16384] */, uint32_t* wsum) {
+__device__ __forceinline__ void fuse_grid_count(const PointGrid& g, const float4* __restrict__ pts, uint32_t* __restrict__ parent,
+                                                uint32_t* __restrict__ cell_count, unsigned long long* __restrict__ slot) {
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= g.n) return;
+  const float4 p = pts[i];
+  const uint32_t cell = (uint32_t)((grid_cz(g, p.z) * g.ny + grid_cy(g, p.y)) * g.nx + grid_cx(g, p.x));
+  const uint32_t rank = atomicAdd(&cell_count[cell], 1u);
+  slot[i] = ((unsigned long long)rank << 32) | cell;
+  parent[i] = i;
+}
+
+__device__ __forceinline__ void fuse_grid_scan_scatter(const PointGrid& g, const float4* __restrict__ pts, uint32_t* __restrict__ cell_count,
+                                                       const unsigned long long* __restrict__ slot, uint32_t* cnt2 /* [33 * 1024] */,
+                                                       uint32_t* wsum) {
   const int tid = threadIdx.x;
   const uint32_t n = g.n, cells = (uint32_t)(g.nx * g.ny * g.nz);
   MKF_STAMP(32);
+  // counters -> LDS, two cells per word, word w at w + w / 32 (lane t then owns 32 words at a stride of 33: no bank conflicts);
+  // four cells per lane and step (the counter array is padded to a multiple of four)
+  uint4* cc4 = reinterpret_cast<uint4*>(cell_count);
 #pragma unroll
-  for (int j = 0; j < 16; ++j) cnt2[j * 1024 + tid] = 0u;
-  __syncthreads();
-  uint32_t cell[16], rk[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const uint32_t i = (uint32_t)s * 1024u + tid;
-    cell[s] = 0u; rk[s] = 0u;
-    if (i < n) {
-      const float4 p = pts[i];
-      cell[s] = (uint32_t)((grid_cz(g, p.z) * g.ny + grid_cy(g, p.y)) * g.nx + grid_cx(g, p.x));
-      const uint32_t sh = (cell[s] & 1u) * 16u;
-      rk[s] = (atomicAdd(&cnt2[cell[s] >> 1], 1u << sh) >> sh) & 0xFFFFu;
-      parent[i] = i;
-    }
+  for (int j = 0; j < 16; ++j) {
+    const uint32_t q = (uint32_t)j * 1024u + tid, c0 = 4u * q;           // cells c0 .. c0 + 3 = words 2 q, 2 q + 1
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (c0 < cells) { v = cc4[q]; cc4[q] = make_uint4(0u, 0u, 0u, 0u); }
+    const uint32_t w = 2u * q;
+    cnt2[w + (w >> 5)] = v.x | (v.y << 16);
+    cnt2[w + 1 + ((w + 1) >> 5)] = v.z | (v.w << 16);
   }
   __syncthreads();
   MKF_STAMP(33);
-  // exclusive scan: lane t owns the cells [32 t, 32 t + 32) = 16 words
-  uint32_t wv[16], sum = 0;
+  uint32_t sum = 0;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    wv[j] = cnt2[tid * 16 + j];
-    sum += (wv[j] & 0xFFFFu) + (wv[j] >> 16);
+  for (int j = 0; j < 32; ++j) {
+    const uint32_t v = cnt2[tid * 33 + j];
+    sum += (v & 0xFFFFu) + (v >> 16);
   }
   uint32_t tot;
   uint32_t run = block_excl_scan<16>(sum, wsum, &tot);
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const uint32_t a = wv[j] & 0xFFFFu, b = wv[j] >> 16;
-    const uint32_t c0 = (uint32_t)tid * 32u + 2u * j;
-    if (c0 < cells) g.cell_start[c0] = run;
-    if (c0 + 1 < cells) g.cell_start[c0 + 1] = run + a;
-    cnt2[tid * 16 + j] = run | ((run + a) << 16);              // (starts <= 16384 fit 16 bits)
+  for (int j = 0; j < 32; ++j) {
+    const uint32_t v = cnt2[tid * 33 + j];
+    const uint32_t a = v & 0xFFFFu, b = v >> 16;
+    cnt2[tid * 33 + j] = run | ((run + a) << 16);              // (starts <= 16384 fit 16 bits)
     run += a + b;
   }
-  if (tid == 0) g.cell_start[cells] = n;
   __syncthreads();
+  uint4* cs4 = reinterpret_cast<uint4*>(g.cell_start);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {                               // coalesced copy-out of the starts
+    const uint32_t q = (uint32_t)j * 1024u + tid, c0 = 4u * q, w = 2u * q;
+    const uint32_t v0 = cnt2[w + (w >> 5)], v1 = cnt2[w + 1 + ((w + 1) >> 5)];
+    if (c0 < cells) cs4[q] = make_uint4(v0 & 0xFFFFu, v0 >> 16, v1 & 0xFFFFu, v1 >> 16);   // (entries past `cells` hold n: the scan ran on)
+  }
+  if (tid == 0) g.cell_start[cells] = n;
   MKF_STAMP(34);
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const uint32_t i = (uint32_t)s * 1024u + tid;
     if (i < n) {
       const float4 p = pts[i];
-      const uint32_t st = (cnt2[cell[s] >> 1] >> ((cell[s] & 1u) * 16u)) & 0xFFFFu;
-      g.sorted[st + rk[s]] = make_float4(p.x, p.y, p.z, __int_as_float((int)i));
+      const unsigned long long sl = slot[i];
+      const uint32_t cell = (uint32_t)sl, wi = cell >> 1;
+      const uint32_t st = (cnt2[wi + (wi >> 5)] >> ((cell & 1u) * 16u)) & 0xFFFFu;
+      g.sorted[st + (uint32_t)(sl >> 32)] = make_float4(p.x, p.y, p.z, __int_as_float((int)i));
     }
   }
   MKF_STAMP(35);
 }
 
-__global__ __launch_bounds__(1024) void k_mkf_pre(MarkParams k, MarkStore s, PointGrid obs, FuseBufs fb, MarkCounters* __restrict__ cnt) {
-  __shared__ uint32_t cnt2[16384];
+// launch 2: one workgroup
+__global__ __launch_bounds__(1024) void k_mkf_grid(PointGrid obs, FuseBufs fb) {
+  __shared__ uint32_t cnt2[33 * 1024];
   __shared__ uint32_t wsum[16];
-  if (blockIdx.x == 0) {
-    if (k.n_obs > 5u) fuse_build_grid(obs, fb.pts, fb.parent, cnt2, wsum);
+  fuse_grid_scan_scatter(obs, fb.pts, fb.cell_count, fb.slot, cnt2, wsum);
+}
+
+__global__ __launch_bounds__(256) void k_mkf_pre(MarkParams k, MarkStore s, PointGrid obs, FuseBufs fb, MarkCounters* __restrict__ cnt,
+                                                 uint32_t nb_count) {
+  if (blockIdx.x < nb_count) {
+    fuse_grid_count(obs, fb.pts, fb.parent, fb.cell_count, fb.slot);
     return;
   }
-  // every slot of the store: no owner yet in this update; alive markings get the window + field-of-view test of
-  // k_mk_fov, one lane each (the double asin / atan2 cost a wave as much as a lane); those inside go on the ray-test list
-  const uint32_t slot = (blockIdx.x - 1u) * 1024u + threadIdx.x;
-  bool inwin = false, inview = false;
+  // every slot of the store: no owner yet in this update; alive markings inside the window (integer test, one lane per
+  // slot) are compacted in LDS, then the field-of-view test of k_mk_fov runs on the dense list (its double asin / atan2
+  // cost a wave as much as a lane: on the sparse slots 512 waves did the work of 128); those in view go on the
+  // ray-test list
+  __shared__ uint32_t lst[256];
+  __shared__ uint32_t wsum[4];
+  const uint32_t slot = (blockIdx.x - nb_count) * 256u + threadIdx.x;
+  bool inwin = false;
   if (slot <= k.table_mask) {
     s.owner[slot] = 0ull;
     if (s.alive[slot]) {
       int x, y, z;
       voxel_unkey(s.keys[slot], &x, &y, &z);
       // map iteration lower_bound(min) .. lower_bound(max): keys in [min, max) on every axis (:487-516)
-      if (!(x < k.wx0 || x >= k.wx1 || y < k.wy0 || y >= k.wy1 || z < k.wz0 || z >= k.wz1)) {
-        inwin = true;
-        const float px = (float)(x * k.res), py = (float)(y * k.res), pz = (float)(z * k.hres);
-        inview = in_lidar_observation(k, px, py, pz);          // outside the sensor's view: stays (:531-540)
-      }
+      inwin = !(x < k.wx0 || x >= k.wx1 || y < k.wy0 || y >= k.wy1 || z < k.wz0 || z >= k.wz1);
     }
   }
-  const unsigned long long bw = __ballot(inwin), bv = __ballot(inview);
-  uint32_t base = 0;
-  if ((threadIdx.x & 63) == 0) {
-    if (bw) atomicAdd(&cnt->n_in_window, (uint32_t)__popcll(bw));
-    if (bv) base = atomicAdd(&cnt->n_clear, (uint32_t)__popcll(bv));
+  uint32_t n_in;
+  const uint32_t at = block_excl_scan<4>(inwin ? 1u : 0u, wsum, &n_in);
+  if (inwin) lst[at] = slot;
+  __syncthreads();
+  if (threadIdx.x == 0 && n_in) atomicAdd(&cnt->n_in_window, n_in);
+  if ((threadIdx.x & ~63u) >= n_in) return;                    // (whole waves leave)
+  bool inview = false;
+  uint32_t sl = 0;
+  if (threadIdx.x < n_in) {
+    sl = lst[threadIdx.x];
+    int x, y, z;
+    voxel_unkey(s.keys[sl], &x, &y, &z);
+    const float px = (float)(x * k.res), py = (float)(y * k.res), pz = (float)(z * k.hres);
+    inview = in_lidar_observation(k, px, py, pz);              // outside the sensor's view: stays (:531-540)
   }
+  const unsigned long long bv = __ballot(inview);
+  uint32_t base = 0;
+  if ((threadIdx.x & 63) == 0 && bv) base = atomicAdd(&cnt->n_clear, (uint32_t)__popcll(bv));
   base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-  if (inview) fb.clear_list[base + lanes_below(bv)] = slot;
+  if (inview) fb.clear_list[base + lanes_below(bv)] = sl;
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 2: selfClear (a wave per listed marking)  |  Euclidean clustering, four lanes per point
+// launch 3: selfClear (a wave per listed marking)  |  Euclidean clustering, four lanes per point
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void cc_union_pair(uint32_t* parent, uint32_t i, uint32_t j) {
   uint32_t u = cc_find(parent, i), v = cc_find(parent, j);
@@ -212,7 +257,7 @@ __global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s,
                                                       MarkCounters* __restrict__ cnt, uint32_t nb_clear) {
   if (blockIdx.x < nb_clear) {
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w < cnt->n_clear) mk_clear_wave(k, s, prev, cnt, fb.clear_list[w], threadIdx.x & 63, fb.removed_on);
+    if (w < cnt->n_clear) mk_clear_wave(k, s, prev, cnt, fb.clear_list[w], threadIdx.x & 63, fb.unmark_pts);
     return;
   }
   // pcl::extractEuclideanClusters as connected components (k_mk_cc_union); the (z, y) rows of a point's tolerance box
@@ -239,10 +284,10 @@ __global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s,
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 3: every point's seed (the smallest point index of its component = the point PCL starts the cluster from);
+// launch 4: every point's seed (the smallest point index of its component = the point PCL starts the cluster from);
 // the per-cluster records of every point index start empty (a cluster is named by its seed's index)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mkf_roots(uint32_t n, uint32_t* parent, ClusterArrays c) {
+__device__ __forceinline__ void fuse_roots(uint32_t n, uint32_t* parent, ClusterArrays c) {
   const uint32_t i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const uint32_t r = cc_find(parent, i);
@@ -286,25 +331,126 @@ __device__ __forceinline__ void ground_ball_wave(const PointGrid& g, float qx, f
   }
 }
 
-// Marking::removePCPtr of one removed marking (k_mk_unmark), generator points recorded by the clearing wave
-__device__ __forceinline__ void fuse_unmark_wave(const MarkParams& k, const MarkStore& s, const PointGrid& ground, const uint2 on, int lane) {
+// ---------------------------------------------------------------------------------------------
+// dGraph / lethal updates, node by node.  The reference walks from every generator point to the ground nodes around it
+// (computeMinDistanceFromObstacle2GroundNodes, removePCPtr); k_mk_dgraph / k_mk_unmark do the same with a wave per
+// point -- half a million scattered device-scope atomics (or small stores) per update onto the few hundred cache lines of
+// the window's nodes, which is what those launches waited for (PMC: waves waiting 99 % of their cycles, 2 % VALU).
+// Turned around, every ground node of the window looks at every point (staged through LDS 256 at a time, a broadcast
+// read per pair) and writes ONCE: the minimum of a set of floats / "any point within the radius" do not depend on the
+// order, and the per-pair arithmetic is the reference's.  Points whose ball leaves the window's range of ground cells
+// (a marking made from another pose, a cloud handed over uncropped) are walked point by point as before.
+// ---------------------------------------------------------------------------------------------
+struct SplatRange {
+  int cx0, cx1, cy0, cy1;     // ground-grid cells of the window (+ inflation radius), every z row
+  uint32_t rows;              // (cy1 - cy0 + 1) * nz
+  uint32_t segs;              // 64-node segments per row (from the longest row of the ground grid)
+};
+__device__ __forceinline__ bool ball_in_range(const PointGrid& g, const SplatRange& rg, float qx, float qy, float r) {
+  return grid_cx(g, qx - r) >= rg.cx0 && grid_cx(g, qx + r) <= rg.cx1 && grid_cy(g, qy - r) >= rg.cy0 && grid_cy(g, qy + r) <= rg.cy1;
+}
+
+// one block = four (row, segment) items of 64 nodes (a wave each) against the source chunks c0, c0 + stride, ...
+template <bool kMark>
+__device__ __forceinline__ void splat_nodes_block(const MarkParams& k, const MarkStore& s, const PointGrid& g, const SplatRange& rg,
+                                                  const float4* __restrict__ src, const uint32_t n_src, const uint32_t item_group,
+                                                  const uint32_t c0, const uint32_t c_stride, float4* stage /* LDS [256] */) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t item = item_group * 4u + (uint32_t)w;
+  bool have = false;
+  float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (item < rg.rows * rg.segs) {
+    const uint32_t row = item / rg.segs, seg = item % rg.segs;
+    const int nyr = rg.cy1 - rg.cy0 + 1;
+    const int cy = rg.cy0 + (int)(row % (uint32_t)nyr), cz = (int)(row / (uint32_t)nyr);
+    const int rb = (cz * g.ny + cy) * g.nx;
+    const uint32_t b = g.cell_start[rb + rg.cx0], e = g.cell_start[rb + rg.cx1 + 1];
+    const uint32_t at = b + seg * 64u + (uint32_t)lane;
+    if (at < e) { nd = g.sorted[at]; have = true; }
+  }
+  const float r2 = static_cast<float>(k.inflation * k.inflation);
+  float dmin = 3.0e38f;
+  bool any = false, close = false;
+  for (uint32_t c = c0; c * 256u < n_src; c += c_stride) {
+    __syncthreads();
+    if (c * 256u + tid < n_src) stage[tid] = src[c * 256u + tid];
+    __syncthreads();
+    const uint32_t m = min(256u, n_src - c * 256u);
+    if (have)
+      for (uint32_t j = 0; j < m; ++j) {
+        const float4 p = stage[j];
+        if (l2_simple(nd.x, nd.y, nd.z, p.x, p.y, p.z) < r2) {
+          const float dx = p.x - nd.x, dy = p.y - nd.y;
+          const float d = sqrtf(dx * dx + dy * dy);                 // z dropped on purpose (cluster_marking.cpp:86-88)
+          any = true;
+          dmin = fminf(dmin, d);
+          if (d <= k.inscribed) close = true;
+        }
+      }
+  }
+  if (!have || !any) return;
+  const int node = __float_as_int(nd.w);
+  if (kMark) {
+    // DynamicGraph::setValue: graph_[key] = min(graph_[key], d); non-negative doubles order like their bit patterns.
+    // (several source chunks may land on one node: atomic; values only fall during the launch, so a plain read that is
+    // already <= d settles it without one)
+    if ((double)dmin < s.dgraph[node])
+      atomicMin(reinterpret_cast<unsigned long long*>(s.dgraph) + node, (unsigned long long)__double_as_longlong((double)dmin));
+    if (close) s.lethal[node] = 1;
+  } else {
+    s.dgraph[node] = 9999.0;                                        // clearValue(node, 9999.0) (:125-138)
+    if (close) s.lethal[node] = 0;
+  }
+}
+
+// the walk from one point, for points whose ball leaves the window's range of ground cells
+template <bool kMark>
+__device__ __forceinline__ void splat_point_wave(const MarkParams& k, const MarkStore& s, const PointGrid& ground, const float4 p, int lane) {
   const float r = (float)k.inflation, r2 = static_cast<float>(k.inflation * k.inflation);
-  for (uint32_t i = 0; i < on.y; ++i) {
-    const float4 p = s.pool[on.x + i];
-    ground_ball_wave(ground, p.x, p.y, p.z, r + 1e-4f, lane, [&](const float4 g) {
-      if (l2_simple(g.x, g.y, g.z, p.x, p.y, p.z) < r2) {
-        const int node = __float_as_int(g.w);
-        const float dx = p.x - g.x, dy = p.y - g.y;
-        const float d = sqrtf(dx * dx + dy * dy);
+  ground_ball_wave(ground, p.x, p.y, p.z, r + 1e-4f, lane, [&](const float4 g) {
+    if (l2_simple(g.x, g.y, g.z, p.x, p.y, p.z) < r2) {
+      const int node = __float_as_int(g.w);
+      const float dx = p.x - g.x, dy = p.y - g.y;
+      const float d = sqrtf(dx * dx + dy * dy);
+      if (kMark) {
+        atomicMin(reinterpret_cast<unsigned long long*>(s.dgraph) + node, (unsigned long long)__double_as_longlong((double)d));
+        if (d <= k.inscribed) s.lethal[node] = 1;
+      } else {
         s.dgraph[node] = 9999.0;
         if (d <= k.inscribed) s.lethal[node] = 0;
       }
-    });
+    }
+  });
+}
+
+// launch 4: seeds  |  removePCPtr of the markings launch 3 cleared: node by node, and point by point for the points
+// outside the window's range
+__global__ __launch_bounds__(256) void k_mkf_roots_unmark(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
+                                                          const MarkCounters* __restrict__ cnt, SplatRange rg, uint32_t nb_roots,
+                                                          uint32_t nb_items, uint32_t nb_chunks) {
+  __shared__ float4 stage[256];
+  if (blockIdx.x < nb_roots) {
+    fuse_roots(k.n_obs, fb.parent, c);
+    return;
+  }
+  const uint32_t n_src = cnt->n_unmark_pts;
+  uint32_t bi = blockIdx.x - nb_roots;
+  if (bi < nb_items * nb_chunks) {
+    splat_nodes_block<false>(k, s, ground, rg, fb.unmark_pts, n_src, bi % nb_items, bi / nb_items, nb_chunks, stage);
+    return;
+  }
+  bi -= nb_items * nb_chunks;
+  const int lane = threadIdx.x & 63;
+  const uint32_t stride = (gridDim.x - nb_roots - nb_items * nb_chunks) * 4u;
+  const float r = (float)k.inflation + 1e-4f;
+  for (uint32_t h = bi * 4u + (threadIdx.x >> 6); h < n_src; h += stride) {
+    const float4 p = fb.unmark_pts[h];
+    if (!ball_in_range(ground, rg, p.x, p.y, r)) splat_point_wave<false>(k, s, ground, p, lane);
   }
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 4, blocks 0..63: one partition of the clusters, everything in LDS
+// launch 5, blocks 0..63: one partition of the clusters, everything in LDS
 // ---------------------------------------------------------------------------------------------
 struct PartLds {              // carve-up of the dynamic LDS of a partition workgroup
   float *px, *py, *pz;        // [P] the partition's points (index order); second half: projected 0.2 m voxel centroids
@@ -606,7 +752,7 @@ __device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBu
     const float cntf = (float)(e - j);
     fb.ds[ds_base + L.rk[j]] = make_float4(sx / cntf, sy / cntf, sz / cntf, __int_as_float((int)cj));
   }
-  __threadfence();
+  wait_own_memory_ops();                                       // (read back below by other lanes of this workgroup: same CU, same L1)
   __syncthreads();
   MKF_STAMP(5);
   // ---- P5: "is it part of the static map", voxel key, in the sensor's view (k_mk_cluster_stage2; :375-430) ----
@@ -766,24 +912,19 @@ __device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBu
 }
 
 __global__ __launch_bounds__(kPartThreads) void k_mkf_groups(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
-                                                             PointGrid map, uint32_t n_map, MarkCounters* __restrict__ cnt, uint32_t n_parts) {
+                                                             PointGrid map, uint32_t n_map, MarkCounters* __restrict__ cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fuse_lds[];
-  if (blockIdx.x < n_parts) {
-    fuse_partition(k, fb, c, s, ground, map, n_map, cnt, fuse_lds);
-    return;
-  }
-  const int lane = threadIdx.x & 63;
-  const uint32_t stride = (gridDim.x - n_parts) * 4u, n_removed = cnt->n_removed;
-  for (uint32_t r = (blockIdx.x - n_parts) * 4u + (threadIdx.x >> 6); r < n_removed; r += stride)
-    fuse_unmark_wave(k, s, ground, fb.removed_on[r], lane);
+  fuse_partition(k, fb, c, s, ground, map, n_map, cnt, fuse_lds);
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 5: the keeper of every claimed voxel stores its generator points (k_mk_commit)  |  dGraph / lethal update of
+// launch 6: the keeper of every claimed voxel stores its generator points (k_mk_commit)  |  dGraph / lethal update of
 // the new generator points (k_mk_dgraph); the last block to finish publishes the counters and leaves them zeroed
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mkf_commit_dgraph(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
-                                                           MarkCounters* __restrict__ cnt, uint32_t nb_commit) {
+                                                           MarkCounters* __restrict__ cnt, SplatRange rg, uint32_t nb_commit,
+                                                           uint32_t nb_items, uint32_t nb_chunks) {
+  __shared__ float4 stage[256];
   const int lane = threadIdx.x & 63;
   const bool fallback = cnt->fallback != 0u;
   if (fallback) {
@@ -814,31 +955,29 @@ __global__ __launch_bounds__(256) void k_mkf_commit_dgraph(MarkParams k, FuseBuf
       }
     }
   } else {
-    const uint32_t n_gen = cnt->n_groups3, nb_dg = gridDim.x - nb_commit;
-    const float r = (float)k.inflation, r2 = static_cast<float>(k.inflation * k.inflation);
-    for (uint32_t h = (blockIdx.x - nb_commit) * 4 + (threadIdx.x >> 6); h < n_gen; h += nb_dg * 4) {
-      const float4 p = fb.gen[h];
-      // computeMinDistanceFromObstacle2GroundNodes + DynamicGraph::setValue + lethal_map_ (cluster_marking.cpp:66-123)
-      ground_ball_wave(ground, p.x, p.y, p.z, r + 1e-4f, lane, [&](const float4 g) {
-        if (l2_simple(g.x, g.y, g.z, p.x, p.y, p.z) < r2) {
-          const int node = __float_as_int(g.w);
-          const float dx = p.x - g.x, dy = p.y - g.y;
-          const float d = sqrtf(dx * dx + dy * dy);                    // z dropped on purpose (:86-88)
-          // setValue: graph_[key] = min(graph_[key], d); non-negative doubles order like their bit patterns
-          atomicMin(reinterpret_cast<unsigned long long*>(s.dgraph) + node, (unsigned long long)__double_as_longlong((double)d));
-          if (d <= k.inscribed) s.lethal[node] = 1;
-        }
-      });
+    const uint32_t n_gen = cnt->n_groups3;
+    uint32_t bi = blockIdx.x - nb_commit;
+    if (bi < nb_items * nb_chunks) {
+      // computeMinDistanceFromObstacle2GroundNodes + DynamicGraph::setValue + lethal_map_ (cluster_marking.cpp:66-123), node by node
+      splat_nodes_block<true>(k, s, ground, rg, fb.gen, n_gen, bi % nb_items, bi / nb_items, nb_chunks, stage);
+    } else {
+      bi -= nb_items * nb_chunks;
+      const uint32_t stride = (gridDim.x - nb_commit - nb_items * nb_chunks) * 4u;
+      const float r = (float)k.inflation + 1e-4f;
+      for (uint32_t h = bi * 4u + (threadIdx.x >> 6); h < n_gen; h += stride) {
+        const float4 p = fb.gen[h];
+        if (!ball_in_range(ground, rg, p.x, p.y, r)) splat_point_wave<true>(k, s, ground, p, lane);
+      }
     }
   }
   // ---- last block out: counters -> host-mapped record, device copy zeroed (the pool fill carries over) ----
+  // (only the counters cross workgroups inside this launch: device-scope atomics, read back with sc1 loads)
   __shared__ uint32_t last;
-  __threadfence();
+  wait_own_memory_ops();
   __syncthreads();
   if (threadIdx.x == 0) last = atomicAdd(&fb.ticket[0], 1u) == gridDim.x - 1u ? 1u : 0u;
   __syncthreads();
   if (!last) return;
-  __threadfence();
   constexpr int kWords = (int)(sizeof(MarkCounters) / sizeof(uint32_t));
   uint32_t* src = reinterpret_cast<uint32_t*>(cnt);
   uint32_t* dst = reinterpret_cast<uint32_t*>(fb.host_out);

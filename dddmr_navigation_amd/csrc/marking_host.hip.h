@@ -17,6 +17,7 @@ constexpr uint32_t kMarkMaxObs = 1u << 20;   // points of one observation (20-bi
 struct GridBuf {              // a PointGrid with its storage
   PointGrid g;
   uint32_t cap_cells = 0, cap_points = 0;
+  uint32_t max_row = 0;       // static grids: points of the fullest (y, z) row of cells
 };
 
 struct MarkingState {
@@ -48,8 +49,9 @@ struct MarkingState {
   hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
   uint32_t seq = 0;
   // fused route (marking_fused.hip.h)
-  uint2* removed_on = nullptr;             // [table]
+  float4* unmark_pts = nullptr;            // [pool_cap]
   uint32_t* clear_list = nullptr;          // [table]
+  uint32_t* cell_count = nullptr;          // [kFuseMaxCells], all zero between updates
   bool alive_list_stale = false;           // the fused route keeps no alive list: the general route rebuilds it first
   uint32_t* ticket = nullptr;              // [2]
   MarkCounters* host_out = nullptr;        // host-mapped (hipHostMalloc), host_out_dev = its device address
@@ -85,7 +87,7 @@ void marking_free(MarkingState* m) {
                m->gslot, m->parent, m->keys_a, m->keys_b, m->keys1, m->vals_a, m->vals_b, m->flags, m->incl, m->cid_incl, m->ds,
                m->proj, m->gen, m->ds_first, m->pool_ofs, m->compact_sizes, m->compact_ofs, m->cl.start, m->cl.size, m->cl.centroid,
                m->cl.state, m->cl.ds_count, m->cl.gen_first, m->cl.gen_count, m->cl.slot, m->cl.vkey, m->counters, m->n_groups,
-               m->temp, m->removed_on, m->ticket, m->clear_list};
+               m->temp, m->unmark_pts, m->ticket, m->clear_list, m->cell_count};
   for (void* q : p)
     if (q) (void)hipFree(q);
   if (m->host_out) (void)hipHostFree(m->host_out);
@@ -110,6 +112,11 @@ void grid_shape(PointGrid& g, const float lo[3], const float hi[3], float cell_x
   g.inv_xy = 1.0f / cell_xy;
   g.inv_z = 1.0f / cell_z;
 }
+
+// grid_cx / grid_cy / grid_cz of marking.hip.h on the host (same float operations)
+int host_cx(const PointGrid& g, float x) { return std::min(std::max((int)std::floor((x - g.ox) * g.inv_xy), 0), g.nx - 1); }
+int host_cy(const PointGrid& g, float y) { return std::min(std::max((int)std::floor((y - g.oy) * g.inv_xy), 0), g.ny - 1); }
+int host_cz(const PointGrid& g, float z) { return std::min(std::max((int)std::floor((z - g.oz) * g.inv_z), 0), g.nz - 1); }
 
 int grid_alloc(dddmr_rollout_ctx* ctx, GridBuf& b, uint32_t cap_cells, uint32_t cap_points) {
   b.cap_cells = cap_cells;
@@ -197,6 +204,12 @@ int upload_static(dddmr_rollout_ctx* ctx, MarkingState* m, GridBuf& b, float4** 
   grid_shape(b.g, lo, hi, cell_xy, cell_z, 1u << 22);
   const int rc = grid_alloc(ctx, b, (uint32_t)((size_t)b.g.nx * b.g.ny * b.g.nz), (uint32_t)n);
   if (rc != DDDMR_OK) return rc;
+  {
+    std::vector<uint32_t> rows((size_t)b.g.ny * b.g.nz, 0u);
+    for (size_t i = 0; i < n; ++i) ++rows[(size_t)host_cz(b.g, h[i].z) * b.g.ny + host_cy(b.g, h[i].y)];
+    b.max_row = 0;
+    for (uint32_t r : rows) b.max_row = std::max(b.max_row, r);
+  }
   uint2* slot = nullptr;
   HIPCHK(ctx, hipMalloc(&slot, std::max<size_t>(n, 1) * sizeof(uint2)));
   const int rb = grid_build(ctx, m, b, *dev, (uint32_t)n, slot, ctx->stream);
@@ -358,8 +371,10 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     HIPCHK(ctx, hipMalloc(&m->cl.vkey, 3 * N * sizeof(int)));
     HIPCHK(ctx, hipMalloc(&m->counters, sizeof(MarkCounters)));
     HIPCHK(ctx, hipMalloc(&m->n_groups, 2 * sizeof(uint32_t)));
-    HIPCHK(ctx, hipMalloc(&m->removed_on, (size_t)table * sizeof(uint2)));
+    HIPCHK(ctx, hipMalloc(&m->unmark_pts, (size_t)m->pool_cap * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&m->clear_list, (size_t)table * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->cell_count, (size_t)kFuseMaxCells * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(m->cell_count, 0, (size_t)kFuseMaxCells * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&m->ticket, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(m->ticket, 0, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(m->counters, 0, sizeof(MarkCounters)));
@@ -450,8 +465,8 @@ int store_maintenance(dddmr_rollout_ctx* ctx, MarkingState* m, hipStream_t st) {
   return DDDMR_OK;
 }
 
-// grid over the crop box of the feed (base frame |x|,|y| <= window, z in [0, marking_height]) in the global frame
-void obs_grid_shape(const MarkingState* m, const UpdateFrame& f, uint32_t cap_cells, PointGrid& g, float lo[3], float hi[3]) {
+// the crop box of the feed (base frame |x|,|y| <= window, z in [0, marking_height]) in the global frame, + 0.3 m
+void crop_box(const MarkingState* m, const UpdateFrame& f, float lo[3], float hi[3]) {
   const dddmr_marking_config& c = m->cfg;
   for (int a = 0; a < 3; ++a) { lo[a] = 3.4e38f; hi[a] = -3.4e38f; }
   for (int corner = 0; corner < 8; ++corner) {
@@ -464,6 +479,10 @@ void obs_grid_shape(const MarkingState* m, const UpdateFrame& f, uint32_t cap_ce
       hi[a] = std::max(hi[a], v + 0.3f);
     }
   }
+}
+// grid over it
+void obs_grid_shape(const MarkingState* m, const UpdateFrame& f, uint32_t cap_cells, PointGrid& g, float lo[3], float hi[3]) {
+  crop_box(m, f, lo, hi);
   const float cell = std::max(0.1f, f.k.tol);
   grid_shape(g, lo, hi, cell, cell, cap_cells);
 }
@@ -564,7 +583,7 @@ int update_general(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f
   return DDDMR_OK;
 }
 
-// one update on the fused route: five launches, no copies (marking_fused.hip.h)
+// one update on the fused route: six launches, no copies (marking_fused.hip.h)
 int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, const float4* obs, uint32_t n_obs, bool timed,
                  MarkCounters& out) {
   hipStream_t st = ctx->stream;
@@ -590,26 +609,54 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
     obs_grid_shape(m, f, std::min(gb.cap_cells, kFuseMaxCells), gb.g, lo, hi);
     gb.g.n = n_obs;
   }
-  FuseBufs fb{obs, m->parent, m->ds, m->gen, m->clear_list, m->removed_on, m->ticket, m->host_out_dev};
+  FuseBufs fb{obs, m->parent, m->ds, m->gen, m->clear_list, m->unmark_pts, m->ticket, m->cell_count, m->keys_a, m->host_out_dev};
   const uint32_t n_alive = m->n_alive_host;
-  // 1: observation grid | every store slot: window + FOV test -> ray-test list
-  MK_LAUNCH(m, k_mkf_pre, dim3(1 + (m->table + 1023) / 1024), dim3(1024), 0, st, k, s, gb.g, fb, m->counters);
-  // 2: ray tests | union-find
-  const uint32_t nb_clear = (n_alive + 3) / 4, nb_cc = mark ? (n_obs * 4 + 255) / 256 : 0;
+  // ground cells of the window + inflation radius: the nodes the node-by-node dGraph updates look at
+  SplatRange rg{};
+  {
+    float lo[3], hi[3];
+    crop_box(m, f, lo, hi);
+    const PointGrid& gg = m->ground.g;
+    const float pad = (float)m->cfg.inflation_radius + 0.05f;
+    rg.cx0 = host_cx(gg, lo[0] - pad); rg.cx1 = host_cx(gg, hi[0] + pad);
+    rg.cy0 = host_cy(gg, lo[1] - pad); rg.cy1 = host_cy(gg, hi[1] + pad);
+    rg.rows = (uint32_t)(rg.cy1 - rg.cy0 + 1) * (uint32_t)gg.nz;
+    rg.segs = std::max(1u, (m->ground.max_row + 63u) / 64u);
+  }
+  const uint32_t nb_items = m->n_ground ? (rg.rows * rg.segs + 3u) / 4u : 0u;
+  // 1: cell counts of the observation grid | every store slot: window + FOV test -> ray-test list
+  const uint32_t nb_count = mark ? (n_obs + 255) / 256 : 0;
+  MK_LAUNCH(m, k_mkf_pre, dim3(nb_count + (m->table + 255) / 256), dim3(256), 0, st, k, s, gb.g, fb, m->counters, nb_count);
+  // 2: scan + scatter of the observation grid
+  if (mark) MK_LAUNCH(m, k_mkf_grid, dim3(1), dim3(1024), 0, st, gb.g, fb);
+  // 3: ray tests | union-find
+  uint32_t nb_clear = (n_alive + 3) / 4, nb_cc = mark ? (n_obs * 4 + 255) / 256 : 0;
+#ifdef DDDMR_PHASE_STAMPS
+  // diagnostic build only (results are wrong with either): time the two halves of the launch apart
+  if (const char* e = std::getenv("DDDMR_MKF_EXP")) { if (std::atoi(e) & 1) nb_cc = 0; if (std::atoi(e) & 2) nb_clear = 0; }
+#endif
   if (nb_clear + nb_cc)
     MK_LAUNCH(m, k_mkf_clear_cc, dim3(nb_clear + nb_cc), dim3(256), 0, st, k, s, prev_grid, gb.g, fb, m->counters, nb_clear);
   if (timed) HIPCHK(ctx, hipEventRecord(m->e1, st));
-  // 3: seeds
-  if (mark) MK_LAUNCH(m, k_mkf_roots, dim3((n_obs + 255) / 256), dim3(256), 0, st, n_obs, m->parent, m->cl);
-  // 4: 64 partitions of the clusters | removePCPtr of the cleared markings
-  const uint32_t n_parts = mark ? (uint32_t)kFuseParts : 0u;
-  const uint32_t nb_un = n_alive ? std::min<uint32_t>(192u, (n_alive + 15) / 16) : 0;
-  if (n_parts + nb_un)
-    MK_LAUNCH(m, k_mkf_groups, dim3(n_parts + nb_un), dim3(kPartThreads), kPartLdsBytes, st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map,
-              m->counters, n_parts);
-  // 5: keepers -> pool | dGraph of the new generator points; the last block publishes the counters
-  const uint32_t nb_commit = mark ? (n_obs + 255) / 256 : 0, nb_dg = mark ? std::min<uint32_t>((n_obs + 3) / 4, 2048u) : 1u;
-  MK_LAUNCH(m, k_mkf_commit_dgraph, dim3(nb_commit + nb_dg), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters, nb_commit);
+  // 4: seeds | removePCPtr of the cleared markings (node by node; point by point outside the window's cells)
+  {
+    const uint32_t nb_roots = mark ? (n_obs + 255) / 256 : 0;
+    const uint32_t chunks = n_alive ? std::min<uint32_t>(16u, (m->pool_used_host + 255) / 256) : 0, nb_far = n_alive ? 64u : 0u;
+    if (nb_roots + nb_items * chunks + nb_far)
+      MK_LAUNCH(m, k_mkf_roots_unmark, dim3(nb_roots + nb_items * chunks + nb_far), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters,
+                rg, nb_roots, chunks ? nb_items : 0u, chunks);
+  }
+  // 5: 64 partitions of the clusters
+  if (mark)
+    MK_LAUNCH(m, k_mkf_groups, dim3(kFuseParts), dim3(kPartThreads), kPartLdsBytes, st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map,
+              m->counters);
+  // 6: keepers -> pool | dGraph of the new generator points (node by node); the last block publishes the counters
+  {
+    const uint32_t nb_commit = mark ? (n_obs + 255) / 256 : 0;
+    const uint32_t chunks = mark ? std::min<uint32_t>(24u, (n_obs + 255) / 256) : 0, nb_far = mark ? 64u : 1u;
+    MK_LAUNCH(m, k_mkf_commit_dgraph, dim3(nb_commit + nb_items * chunks + nb_far), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters,
+              rg, nb_commit, chunks ? nb_items : 0u, chunks);
+  }
   if (timed) HIPCHK(ctx, hipEventRecord(m->e2, st));
   HIPCHK(ctx, hipStreamSynchronize(st));
   HIPCHK(ctx, hipGetLastError());
@@ -774,6 +821,9 @@ int dddmr_rollout_marking_route_counts(dddmr_rollout_ctx* ctx, uint32_t* updates
 // diagnostic build only: phase stamps of the last fused update's two single-workgroup blocks
 int dddmr_rollout_diag_mkstamps(unsigned long long* out, size_t n_words) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(dddmr::g_mk_stamps), n_words * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+int dddmr_rollout_diag_mkclear(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(dddmr::g_mk_clear_cyc), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif
 

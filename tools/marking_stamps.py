@@ -36,3 +36,10 @@ with LocalPlanner([sc.theory], max_points=1 << 16) as lp:
     print("grid block:")
     for i in range(33, 36):
         print(f"  {gn[i]:24s} {(acc[i] - acc[i-1]) / 1000.0:9.2f}")
+    cyc = np.zeros(8, dtype=np.uint64)
+    lib.dddmr_rollout_diag_mkclear.argtypes = [C.c_void_p]
+    assert lib.dddmr_rollout_diag_mkclear(cyc.ctypes.data_as(C.c_void_p)) == 0
+    c = cyc.astype(np.float64)
+    r = max(c[0], 1)
+    print(f"ray tests over 30 updates: {int(c[0])} rays, {c[1] / r:.2f} chunks probed per ray; kilo-ticks per ray: lay-out {c[2] / r / 1e3:.2f}, "
+          f"probes {c[3] / r / 1e3:.2f}, near test {c[4] / r / 1e3:.2f}, removal {c[5] / r / 1e3:.2f}")
