@@ -135,7 +135,8 @@ struct MarkCounters {         // device counters of one update (copied back for 
   uint32_t fallback;     // fused route: a partition or its voxel sort keys did not fit, the mark phase has to take the general route
   uint32_t n_clear;      // fused route: stored markings inside the window and the sensor's view (entries of the ray-test list)
   uint32_t n_revived;    // fused route: markings that went from not alive to alive in the commit
-  uint32_t n_unmark_pts; // fused route: generator points of the markings this update's selfClear removed
+  uint32_t n_unmark_pts; // fused route: generator points of removed markings that have to be walked point by point
+  uint32_t n_cleared_shard[32];   // fused route: removals, counted in shards (their sum = n_cleared)
 };
 
 // isinLidarObservation (:682-746).  The reference builds a rotation that turns the x axis onto the viewing
@@ -230,11 +231,13 @@ __device__ unsigned long long g_mk_clear_cyc[8];   // diagnostic build: [0] rays
 #define MKC_NOW() 0ll
 #define MKC_ADD(i, v) do { (void)sizeof(v); } while (0)
 #endif
-// The ray test of one stored marking by one wave.  unmark_pts (the fused route, marking_fused.hip.h): the generator
-// points of a removed marking are copied to a flat list (that route's removePCPtr runs ground node by ground node over
-// all of them, and its commit may hand the slot to a new cluster meanwhile).
-__device__ __forceinline__ void mk_clear_wave(const MarkParams& k, const MarkStore& s, const PointGrid& prev, MarkCounters* __restrict__ cnt,
-                                              const uint32_t slot, const int lane, float4* __restrict__ unmark_pts) {
+// The ray test of one stored marking by one wave; true (wave-uniform) when the marking was removed.
+// kListed: the removed slot goes on MarkStore::removed_list (what k_mk_unmark walks) and is counted in n_cleared / n_removed,
+// two same-address device-scope atomics per removal (~12 ns each, one after the other: 1400 removals = 30 us of the
+// launch).  The fused route keeps no such list and counts removals in 32 shards of n_cleared_shard instead.
+template <bool kListed>
+__device__ __forceinline__ bool mk_clear_wave(const MarkParams& k, const MarkStore& s, const PointGrid& prev, MarkCounters* __restrict__ cnt,
+                                              const uint32_t slot, const int lane) {
   int x, y, z;
   voxel_unkey(s.keys[slot], &x, &y, &z);
   const float px = (float)(x * k.res), py = (float)(y * k.res), pz = (float)(z * k.hres);
@@ -292,7 +295,7 @@ __device__ __forceinline__ void mk_clear_wave(const MarkParams& k, const MarkSto
   }
   const long long mkc2 = MKC_NOW();
   MKC_ADD(3, mkc2 - mkc0);
-  if (blocked) return;                                              // the ray is blocked: keep (:582-591)
+  if (blocked) return false;                                        // the ray is blocked: keep (:582-591)
   int near = 0;
   if (!observation_clear) {
     const float r2 = static_cast<float>(k.res * k.res);
@@ -300,26 +303,24 @@ __device__ __forceinline__ void mk_clear_wave(const MarkParams& k, const MarkSto
   }
   const long long mkc3 = MKC_NOW();
   MKC_ADD(4, mkc3 - mkc2);
-  if (near > 1) return;                                             // still observed (:596-605)
-  uint32_t base = 0;
+  if (near > 1) return false;                                       // still observed (:596-605)
   if (lane == 0) {                                                  // Marking::removePCPtr
     s.alive[slot] = 0;
     s.removed_seq[slot] = k.seq;
-    atomicAdd(&cnt->n_cleared, 1u);
-    s.removed_list[atomicAdd(&cnt->n_removed, 1u)] = slot;
-    if (unmark_pts) base = atomicAdd(&cnt->n_unmark_pts, s.pts_n[slot]);
-  }
-  if (unmark_pts) {                                                 // its generator points, for the node-by-node removePCPtr
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    const uint32_t ofs = s.pts_ofs[slot], n = s.pts_n[slot];
-    for (uint32_t i = lane; i < n; i += 64) unmark_pts[base + i] = s.pool[ofs + i];
+    if (kListed) {
+      atomicAdd(&cnt->n_cleared, 1u);
+      s.removed_list[atomicAdd(&cnt->n_removed, 1u)] = slot;
+    } else {
+      atomicAdd(&cnt->n_cleared_shard[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 31u], 1u);
+    }
   }
   MKC_ADD(5, MKC_NOW() - mkc3);
+  return true;
 }
 __global__ __launch_bounds__(256) void k_mk_clear(MarkParams k, MarkStore s, PointGrid prev, MarkCounters* __restrict__ cnt) {
   const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (w >= k.n_alive_prev || !s.fov_flag[w]) return;
-  mk_clear_wave(k, s, prev, cnt, s.alive_list[w], threadIdx.x & 63, nullptr);
+  (void)mk_clear_wave<true>(k, s, prev, cnt, s.alive_list[w], threadIdx.x & 63);
 }
 
 // removePCPtr's loop over nodes_of_min_distance_, recomputed from the marking's generator points: every ground node

@@ -49,14 +49,44 @@ __device__ unsigned long long g_mk_stamps[64];
 #define MKF_STAMP(i) do { } while (0)
 #endif
 
+
+constexpr uint32_t kBandMax = 128;      // y rows of ground cells the window's range may span (else: point by point)
+constexpr uint32_t kBandCap = 16384;    // points one band takes (more: point by point)
+
+struct SplatRange {
+  int cx0, cx1, cy0, cy1;     // ground-grid cells of the window (+ inflation radius), every z row
+  uint32_t rows;              // (cy1 - cy0 + 1) * nz
+  uint32_t segs;              // 64-node segments per row (from the longest row of the ground grid)
+  int delta;                  // a node of row cy can only be within the radius of points of the rows cy - delta .. cy + delta
+  uint32_t bands;             // cy1 - cy0 + 1, or 0: banding off (the range spans more than kBandMax rows)
+};
+struct BandList {             // points bucketed by the y row of ground cells they fall in (relative to cy0)
+  float4* pts;                // [kBandMax * kBandCap]
+  uint32_t* cnt;              // [kBandMax], all zero between updates
+};
+__device__ __forceinline__ bool ball_in_range(const PointGrid& g, const SplatRange& rg, float qx, float qy, float r) {
+  return grid_cx(g, qx - r) >= rg.cx0 && grid_cx(g, qx + r) <= rg.cx1 && grid_cy(g, qy - r) >= rg.cy0 && grid_cy(g, qy + r) <= rg.cy1;
+}
+// true: the point went into its band (the node-by-node pass will see it); false: it has to be walked point by point
+__device__ __forceinline__ bool band_push(const PointGrid& g, const SplatRange& rg, const BandList& b, const float4 p, const float r) {
+  if (!rg.bands || !ball_in_range(g, rg, p.x, p.y, r)) return false;
+  const uint32_t band = (uint32_t)(grid_cy(g, p.y) - rg.cy0);
+  const uint32_t at = atomicAdd(&b.cnt[band], 1u);
+  if (at >= kBandCap) return false;
+  b.pts[(size_t)band * kBandCap + at] = p;
+  return true;
+}
+
 struct FuseBufs {
   const float4* pts;       // this update's observation (global frame)
   uint32_t* parent;        // [n] union-find; after k_mkf_roots: every point's seed
   float4* ds;              // [n] 0.2 m voxel centroids, w = cluster (scratch of a partition between its two halves)
   float4* gen;             // [n] generator points, w = cluster
   uint32_t* clear_list;    // [table] slots inside the window and the sensor's view
-  float4* unmark_pts;      // [pool] generator points of the markings this update's selfClear removed
-  uint32_t* ticket;        // [2]
+  float4* unmark_pts;      // [pool] generator points of removed markings that have to be walked point by point
+  BandList gen_bands, unmark_bands;
+  SplatRange rg;
+  uint32_t* ticket;        // [34] top counter, spare, 32 shards
   uint32_t* cell_count;    // [kFuseMaxCells] all zero between updates
   unsigned long long* slot;  // [n] (rank << 32) | cell of a point in the observation grid
   MarkCounters* host_out;  // host-mapped copy of the update's counters
@@ -253,11 +283,35 @@ __device__ __forceinline__ void cc_union_pair(uint32_t* parent, uint32_t i, uint
   }
 }
 
-__global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s, PointGrid prev, PointGrid obs, FuseBufs fb,
+__global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s, PointGrid prev, PointGrid obs, PointGrid ground, FuseBufs fb,
                                                       MarkCounters* __restrict__ cnt, uint32_t nb_clear) {
   if (blockIdx.x < nb_clear) {
     const uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w < cnt->n_clear) mk_clear_wave(k, s, prev, cnt, fb.clear_list[w], threadIdx.x & 63, fb.unmark_pts);
+    if (w < cnt->n_clear) {
+      const uint32_t slot = fb.clear_list[w];
+      const int lane = threadIdx.x & 63;
+      if (mk_clear_wave<false>(k, s, prev, cnt, slot, lane)) {
+        // the generator points of the removed marking, for this update's removePCPtr (launches 4 / 5): into the band of
+        // the row of ground cells they fall in, or onto the list of points to be walked one by one.  (Copied now: the
+        // commit of launch 6 may hand the slot to a new cluster.)
+        const uint32_t ofs = s.pts_ofs[slot], n = s.pts_n[slot];
+        const float r = (float)k.inflation + 1e-4f;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+          const uint32_t i = i0 + (uint32_t)lane;
+          bool walk = false;
+          float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (i < n) {
+            p = s.pool[ofs + i];
+            walk = !band_push(ground, fb.rg, fb.unmark_bands, p, r);
+          }
+          const unsigned long long bw = __ballot(walk);
+          uint32_t base = 0;
+          if (lane == 0 && bw) base = atomicAdd(&cnt->n_unmark_pts, (uint32_t)__popcll(bw));
+          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+          if (walk) fb.unmark_pts[base + lanes_below(bw)] = p;
+        }
+      }
+    }
     return;
   }
   // pcl::extractEuclideanClusters as connected components (k_mk_cc_union); the (z, y) rows of a point's tolerance box
@@ -336,64 +390,78 @@ __device__ __forceinline__ void ground_ball_wave(const PointGrid& g, float qx, f
 // (computeMinDistanceFromObstacle2GroundNodes, removePCPtr); k_mk_dgraph / k_mk_unmark do the same with a wave per
 // point -- half a million scattered device-scope atomics (or small stores) per update onto the few hundred cache lines of
 // the window's nodes, which is what those launches waited for (PMC: waves waiting 99 % of their cycles, 2 % VALU).
-// Turned around, every ground node of the window looks at every point (staged through LDS 256 at a time, a broadcast
-// read per pair) and writes ONCE: the minimum of a set of floats / "any point within the radius" do not depend on the
-// order, and the per-pair arithmetic is the reference's.  Points whose ball leaves the window's range of ground cells
-// (a marking made from another pose, a cloud handed over uncropped) are walked point by point as before.
+// Turned around, every ground node of the window looks at the points that can reach it -- the points are dropped into
+// bands (the y row of ground cells they fall in) as they are made, a node's row reads the 2 delta + 1 bands around it,
+// staged through LDS 256 at a time, a broadcast read per pair -- and writes ONCE: the minimum of a set of floats / "any
+// point within the radius" do not depend on the order, and the per-pair arithmetic is the reference's.  Points whose
+// ball leaves the window's range of ground cells (a marking made from another pose, a cloud handed over uncropped) or
+// that find their band full are walked point by point as before.
 // ---------------------------------------------------------------------------------------------
-struct SplatRange {
-  int cx0, cx1, cy0, cy1;     // ground-grid cells of the window (+ inflation radius), every z row
-  uint32_t rows;              // (cy1 - cy0 + 1) * nz
-  uint32_t segs;              // 64-node segments per row (from the longest row of the ground grid)
-};
-__device__ __forceinline__ bool ball_in_range(const PointGrid& g, const SplatRange& rg, float qx, float qy, float r) {
-  return grid_cx(g, qx - r) >= rg.cx0 && grid_cx(g, qx + r) <= rg.cx1 && grid_cy(g, qy - r) >= rg.cy0 && grid_cy(g, qy + r) <= rg.cy1;
-}
-
-// one block = four (row, segment) items of 64 nodes (a wave each) against the source chunks c0, c0 + stride, ...
+// one block = up to four 64-node segments of one row of ground cells (a wave each) against every `n_part`-th 256-point
+// chunk of the bands that can reach the row
 template <bool kMark>
-__device__ __forceinline__ void splat_nodes_block(const MarkParams& k, const MarkStore& s, const PointGrid& g, const SplatRange& rg,
-                                                  const float4* __restrict__ src, const uint32_t n_src, const uint32_t item_group,
-                                                  const uint32_t c0, const uint32_t c_stride, float4* stage /* LDS [256] */) {
+__device__ __forceinline__ void splat_band_block(const MarkParams& k, const MarkStore& s, const PointGrid& g, const SplatRange& rg,
+                                                 const BandList& bl, const uint32_t row, const uint32_t seg_group, const uint32_t part,
+                                                 const uint32_t n_part, float4* stage /* LDS [256] */) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const uint32_t item = item_group * 4u + (uint32_t)w;
+  const int nyr = rg.cy1 - rg.cy0 + 1;
+  const int cy = rg.cy0 + (int)(row % (uint32_t)nyr), cz = (int)(row / (uint32_t)nyr);
+  const uint32_t seg = seg_group * 4u + (uint32_t)w;
   bool have = false;
   float4 nd = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (item < rg.rows * rg.segs) {
-    const uint32_t row = item / rg.segs, seg = item % rg.segs;
-    const int nyr = rg.cy1 - rg.cy0 + 1;
-    const int cy = rg.cy0 + (int)(row % (uint32_t)nyr), cz = (int)(row / (uint32_t)nyr);
+  {
     const int rb = (cz * g.ny + cy) * g.nx;
     const uint32_t b = g.cell_start[rb + rg.cx0], e = g.cell_start[rb + rg.cx1 + 1];
     const uint32_t at = b + seg * 64u + (uint32_t)lane;
-    if (at < e) { nd = g.sorted[at]; have = true; }
+    if (seg < rg.segs && at < e) { nd = g.sorted[at]; have = true; }
   }
+  // Per pair the reference tests the 3-D distance (FLANN's L2_Simple: dx^2, + dy^2, + dz^2) against the squared radius and
+  // then takes d = sqrtf(dx^2 + dy^2) -- the partial sum after two terms of the very same accumulation.  sqrtf is
+  // monotone, so the minimum of d over the hits is sqrtf of the minimum partial sum, and "some d <= inscribed radius" is
+  // "the minimum d <= it": the loop keeps one float minimum, branch-free (11 VALU per pair; with the sqrtf and the
+  // compares under a per-pair branch a wave spent 36).
   const float r2 = static_cast<float>(k.inflation * k.inflation);
-  float dmin = 3.0e38f;
-  bool any = false, close = false;
-  for (uint32_t c = c0; c * 256u < n_src; c += c_stride) {
-    __syncthreads();
-    if (c * 256u + tid < n_src) stage[tid] = src[c * 256u + tid];
-    __syncthreads();
-    const uint32_t m = min(256u, n_src - c * 256u);
-    if (have)
-      for (uint32_t j = 0; j < m; ++j) {
-        const float4 p = stage[j];
-        if (l2_simple(nd.x, nd.y, nd.z, p.x, p.y, p.z) < r2) {
-          const float dx = p.x - nd.x, dy = p.y - nd.y;
-          const float d = sqrtf(dx * dx + dy * dy);                 // z dropped on purpose (cluster_marking.cpp:86-88)
-          any = true;
-          dmin = fminf(dmin, d);
-          if (d <= k.inscribed) close = true;
+  float min_d2 = 3.0e38f;
+  // the fills of the (at most 2 delta + 1) bands in reach, one lane each
+  const int b_lo = max(cy - rg.delta, rg.cy0), b_hi = min(cy + rg.delta, rg.cy1);
+  const uint32_t my_n = (b_lo + lane <= b_hi && lane < 64) ? min(bl.cnt[b_lo + lane - rg.cy0], kBandCap) : 0u;
+  uint32_t ci = 0;
+  for (int band = b_lo; band <= b_hi; ++band) {
+    const uint32_t n_b = (uint32_t)__builtin_amdgcn_readlane((int)my_n, band - b_lo);
+    const float4* src = bl.pts + (size_t)(band - rg.cy0) * kBandCap;
+    for (uint32_t c0 = 0; c0 < n_b; c0 += 256u, ++ci) {
+      if (ci % n_part != part) continue;
+      __syncthreads();
+      stage[tid] = c0 + tid < n_b ? src[c0 + tid] : make_float4(3.0e18f, 3.0e18f, 3.0e18f, 0.f);    // (padding: out of any ball)
+      __syncthreads();
+      const uint32_t m = min(256u, n_b - c0);
+      if (have)
+        for (uint32_t j = 0; j < m; j += 8) {                    // eight broadcast reads in flight per step
+          float4 pp[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) pp[u] = stage[j + u];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            float d = fsub(nd.x, pp[u].x);
+            float acc = fmul(d, d);
+            d = fsub(nd.y, pp[u].y);
+            acc = fadd(acc, fmul(d, d));
+            const float d2 = acc;                                // dx^2 + dy^2
+            d = fsub(nd.z, pp[u].z);
+            acc = fadd(acc, fmul(d, d));                         // l2_simple(node, point)
+            min_d2 = fminf(min_d2, acc < r2 ? d2 : 3.0e38f);
+          }
         }
-      }
+    }
   }
-  if (!have || !any) return;
+  if (!have || !(min_d2 < 3.0e38f)) return;
+  const float dmin = sqrtf(min_d2);                              // z dropped on purpose (cluster_marking.cpp:86-88)
+  const bool close = dmin <= k.inscribed;
   const int node = __float_as_int(nd.w);
   if (kMark) {
     // DynamicGraph::setValue: graph_[key] = min(graph_[key], d); non-negative doubles order like their bit patterns.
-    // (several source chunks may land on one node: atomic; values only fall during the launch, so a plain read that is
-    // already <= d settles it without one)
+    // (several blocks may land on one node: atomic; values only fall during the launch, so a plain read that is already
+    // <= d settles it without one)
     if ((double)dmin < s.dgraph[node])
       atomicMin(reinterpret_cast<unsigned long long*>(s.dgraph) + node, (unsigned long long)__double_as_longlong((double)dmin));
     if (close) s.lethal[node] = 1;
@@ -402,6 +470,7 @@ __device__ __forceinline__ void splat_nodes_block(const MarkParams& k, const Mar
     if (close) s.lethal[node] = 0;
   }
 }
+
 
 // the walk from one point, for points whose ball leaves the window's range of ground cells
 template <bool kMark>
@@ -423,30 +492,26 @@ __device__ __forceinline__ void splat_point_wave(const MarkParams& k, const Mark
   });
 }
 
-// launch 4: seeds  |  removePCPtr of the markings launch 3 cleared: node by node, and point by point for the points
-// outside the window's range
+// launch 4: seeds  |  removePCPtr of the markings launch 3 cleared: ground node by ground node, and point by point for
+// the points that found no band
 __global__ __launch_bounds__(256) void k_mkf_roots_unmark(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
-                                                          const MarkCounters* __restrict__ cnt, SplatRange rg, uint32_t nb_roots,
-                                                          uint32_t nb_items, uint32_t nb_chunks) {
+                                                          const MarkCounters* __restrict__ cnt, uint32_t nb_roots, uint32_t nb_band,
+                                                          uint32_t seg_groups, uint32_t n_part) {
   __shared__ float4 stage[256];
   if (blockIdx.x < nb_roots) {
     fuse_roots(k.n_obs, fb.parent, c);
     return;
   }
-  const uint32_t n_src = cnt->n_unmark_pts;
   uint32_t bi = blockIdx.x - nb_roots;
-  if (bi < nb_items * nb_chunks) {
-    splat_nodes_block<false>(k, s, ground, rg, fb.unmark_pts, n_src, bi % nb_items, bi / nb_items, nb_chunks, stage);
+  if (bi < nb_band) {
+    splat_band_block<false>(k, s, ground, fb.rg, fb.unmark_bands, bi / (seg_groups * n_part), (bi / n_part) % seg_groups, bi % n_part, n_part, stage);
     return;
   }
-  bi -= nb_items * nb_chunks;
+  bi -= nb_band;
+  const uint32_t n_src = cnt->n_unmark_pts;
   const int lane = threadIdx.x & 63;
-  const uint32_t stride = (gridDim.x - nb_roots - nb_items * nb_chunks) * 4u;
-  const float r = (float)k.inflation + 1e-4f;
-  for (uint32_t h = bi * 4u + (threadIdx.x >> 6); h < n_src; h += stride) {
-    const float4 p = fb.unmark_pts[h];
-    if (!ball_in_range(ground, rg, p.x, p.y, r)) splat_point_wave<false>(k, s, ground, p, lane);
-  }
+  const uint32_t stride = (gridDim.x - nb_roots - nb_band) * 4u;
+  for (uint32_t h = bi * 4u + (threadIdx.x >> 6); h < n_src; h += stride) splat_point_wave<false>(k, s, ground, fb.unmark_pts[h], lane);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -840,13 +905,21 @@ __device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBu
     ng3 = lds_group_index(m3, kc, kf, L.state, true, L.rk, L.wsum);
   }
   MKF_STAMP(7);
-  // ---- P7: 0.1 m VoxelGrid of the projected points -> generator points; first / count per cluster ----
+  // ---- P7: 0.1 m VoxelGrid of the projected points -> generator points; first / count per cluster.  Every generator
+  //      point also goes into the band of the row of ground cells it falls in (launch 6 reads them node by node): ranks
+  //      inside the partition from LDS counters, then ONE device-scope atomic per band and partition (a returning
+  //      atomic per point on the ~40 band counters, from 64 partitions at once, cost this phase 15 us) ----
+  uint32_t* band_n = L.hist;                                     // [kBandMax] points of this partition per band
+  uint32_t* band_at = L.hist + kBandMax;                         // [kBandMax] first entry of the partition in the band
+  if (tid < (int)kBandMax) band_n[tid] = 0u;
   if (tid == 0) L.misc[1] = ng3 ? atomicAdd(&cnt->n_groups3, ng3) : 0u;
   __syncthreads();
   const uint32_t gen_base = L.misc[1];
+  const float rball = (float)k.inflation + 1e-4f;
   for (uint32_t j = tid; j < m3; j += 256) {
     const uint32_t cj = kc[j];
     if (j == 0u || kc[j - 1] != cj) L.start[cj] = L.rk[j];       // (start: now the cluster's first generator point)
+    pf[j] = 0xFFFFu;
     if (L.rk[j + 1] == L.rk[j]) continue;
     const uint32_t vox = kf[j];
     float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -856,7 +929,22 @@ __device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBu
       sx += L.px[q]; sy += L.py[q]; sz += L.pz[q];
     }
     const float cntf = (float)(e - j);
-    fb.gen[gen_base + L.rk[j]] = make_float4(sx / cntf, sy / cntf, sz / cntf, __int_as_float((int)L.gci[cj]));
+    const float4 gp = make_float4(sx / cntf, sy / cntf, sz / cntf, __int_as_float((int)L.gci[cj]));
+    fb.gen[gen_base + L.rk[j]] = gp;
+    if (fb.rg.bands && ball_in_range(ground, fb.rg, gp.x, gp.y, rball)) {     // (launch 6 walks the others point by point)
+      const uint32_t band = (uint32_t)(grid_cy(ground, gp.y) - fb.rg.cy0);
+      pf[j] = (uint16_t)band;
+      L.mine[j] = (uint16_t)atomicAdd(&band_n[band], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid < (int)kBandMax && band_n[tid]) band_at[tid] = atomicAdd(&fb.gen_bands.cnt[tid], band_n[tid]);
+  __syncthreads();
+  for (uint32_t j = tid; j < m3; j += 256) {
+    const uint32_t band = pf[j];
+    if (band == 0xFFFFu) continue;
+    const uint32_t at = band_at[band] + L.mine[j];               // (< kBandCap: an update makes at most kFuseMaxObs generator points)
+    fb.gen_bands.pts[(size_t)band * kBandCap + at] = fb.gen[gen_base + L.rk[j]];
   }
   __syncthreads();
   for (uint32_t j = tid; j < m3; j += 256) {
@@ -911,6 +999,7 @@ __device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBu
   MKF_STAMP(9);
 }
 
+// launch 5: 64 partition blocks
 __global__ __launch_bounds__(kPartThreads) void k_mkf_groups(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
                                                              PointGrid map, uint32_t n_map, MarkCounters* __restrict__ cnt) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fuse_lds[];
@@ -922,60 +1011,82 @@ __global__ __launch_bounds__(kPartThreads) void k_mkf_groups(MarkParams k, FuseB
 // the new generator points (k_mk_dgraph); the last block to finish publishes the counters and leaves them zeroed
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mkf_commit_dgraph(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
-                                                           MarkCounters* __restrict__ cnt, SplatRange rg, uint32_t nb_commit,
-                                                           uint32_t nb_items, uint32_t nb_chunks) {
+                                                           MarkCounters* __restrict__ cnt, uint32_t nb_commit, uint32_t nb_band,
+                                                           uint32_t seg_groups, uint32_t n_part) {
   __shared__ float4 stage[256];
   const int lane = threadIdx.x & 63;
   const bool fallback = cnt->fallback != 0u;
   if (fallback) {
     // the mark phase is redone on the general route: nothing of this attempt may reach the store
   } else if (blockIdx.x < nb_commit) {
+    // one lane per point index = possible cluster; the keepers of a wave draw their pool ranges with ONE atomic (3600
+    // keepers drawing one each from the same counter took 40 us: ~12 ns per same-address device-scope atomic)
     const uint32_t gi = blockIdx.x * 256 + threadIdx.x;
+    bool keeper = false;
+    uint32_t slot = 0, ng = 0, first = 0;
     if (gi < k.n_obs && c.state[gi] == 2u) {
-      const uint32_t slot = c.slot[gi];
+      slot = c.slot[gi];
       const unsigned long long pr = ((unsigned long long)((1u << 20) - min(c.size[gi], (1u << 20) - 1u)) << 20) | (unsigned long long)(gi + 1u);
-      if (s.owner[slot] == pr) {
-        const uint32_t ng = c.gen_count[gi], first = c.gen_first[gi];
-        const uint32_t ofs = atomicAdd(&cnt->pool_used, ng);
-        const uint32_t was = s.alive[slot];
-        if (ofs + ng > k.pool_cap) {
-          atomicOr(&cnt->overflow, 2u);
-          s.alive[slot] = 0; s.pts_n[slot] = 0;
-          if (was) atomicAdd(&cnt->n_revived, 0xFFFFFFFFu);
-        } else {
-          for (uint32_t i = 0; i < ng; ++i) {
-            const float4 p = fb.gen[first + i];
-            s.pool[ofs + i] = make_float4(p.x, p.y, p.z, 0.f);
-          }
-          s.pts_ofs[slot] = ofs;
-          s.pts_n[slot] = ng;
-          s.alive[slot] = 1;
-          if (!was) atomicAdd(&cnt->n_revived, 1u);
+      if (s.owner[slot] == pr) { keeper = true; ng = c.gen_count[gi]; first = c.gen_first[gi]; }
+    }
+    const uint32_t incl = wave_incl_scan_u32(ng);
+    const uint32_t tot = wave_last(incl);
+    uint32_t base = 0;
+    if (lane == 0 && tot) base = atomicAdd(&cnt->pool_used, tot);
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    uint32_t revived = 0, killed = 0;
+    if (keeper) {
+      const uint32_t ofs = base + incl - ng;
+      const uint32_t was = s.alive[slot];
+      if (ofs + ng > k.pool_cap) {
+        atomicOr(&cnt->overflow, 2u);
+        s.alive[slot] = 0; s.pts_n[slot] = 0;
+        killed = was ? 1u : 0u;
+      } else {
+        for (uint32_t i = 0; i < ng; ++i) {
+          const float4 p = fb.gen[first + i];
+          s.pool[ofs + i] = make_float4(p.x, p.y, p.z, 0.f);
         }
+        s.pts_ofs[slot] = ofs;
+        s.pts_n[slot] = ng;
+        s.alive[slot] = 1;
+        revived = was ? 0u : 1u;
       }
     }
+    const unsigned long long br = __ballot(revived != 0u), bk = __ballot(killed != 0u);
+    if (lane == 0 && (br | bk)) atomicAdd(&cnt->n_revived, (uint32_t)__popcll(br) - (uint32_t)__popcll(bk));
   } else {
-    const uint32_t n_gen = cnt->n_groups3;
     uint32_t bi = blockIdx.x - nb_commit;
-    if (bi < nb_items * nb_chunks) {
+    if (bi < nb_band) {
       // computeMinDistanceFromObstacle2GroundNodes + DynamicGraph::setValue + lethal_map_ (cluster_marking.cpp:66-123), node by node
-      splat_nodes_block<true>(k, s, ground, rg, fb.gen, n_gen, bi % nb_items, bi / nb_items, nb_chunks, stage);
+      splat_band_block<true>(k, s, ground, fb.rg, fb.gen_bands, bi / (seg_groups * n_part), (bi / n_part) % seg_groups, bi % n_part, n_part, stage);
     } else {
-      bi -= nb_items * nb_chunks;
-      const uint32_t stride = (gridDim.x - nb_commit - nb_items * nb_chunks) * 4u;
+      // ... and point by point for the generator points that went into no band
+      bi -= nb_band;
+      const uint32_t n_gen = cnt->n_groups3, stride = (gridDim.x - nb_commit - nb_band) * 4u;
       const float r = (float)k.inflation + 1e-4f;
       for (uint32_t h = bi * 4u + (threadIdx.x >> 6); h < n_gen; h += stride) {
         const float4 p = fb.gen[h];
-        if (!ball_in_range(ground, rg, p.x, p.y, r)) splat_point_wave<true>(k, s, ground, p, lane);
+        if (!fb.rg.bands || !ball_in_range(ground, fb.rg, p.x, p.y, r)) splat_point_wave<true>(k, s, ground, p, lane);
       }
     }
   }
   // ---- last block out: counters -> host-mapped record, device copy zeroed (the pool fill carries over) ----
-  // (only the counters cross workgroups inside this launch: device-scope atomics, read back with sc1 loads)
+  // (only the counters cross workgroups inside this launch: device-scope atomics, read back with sc1 loads).  Two-level
+  // ticket: 32 shard counters, then one -- 2000 blocks drawing from ONE counter took 25 us (~12 ns per same-address
+  // device-scope atomic, one after the other).
   __shared__ uint32_t last;
   wait_own_memory_ops();
   __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(&fb.ticket[0], 1u) == gridDim.x - 1u ? 1u : 0u;
+  if (threadIdx.x == 0) {
+    const uint32_t shard = blockIdx.x & 31u, in_shard = (gridDim.x - shard + 31u) / 32u;
+    uint32_t l = 0;
+    if (atomicAdd(&fb.ticket[2 + shard], 1u) == in_shard - 1u) {
+      fb.ticket[2 + shard] = 0u;
+      l = atomicAdd(&fb.ticket[0], 1u) == min(gridDim.x, 32u) - 1u ? 1u : 0u;
+    }
+    last = l;
+  }
   __syncthreads();
   if (!last) return;
   constexpr int kWords = (int)(sizeof(MarkCounters) / sizeof(uint32_t));
@@ -986,6 +1097,7 @@ __global__ __launch_bounds__(256) void k_mkf_commit_dgraph(MarkParams k, FuseBuf
     __hip_atomic_store(&dst[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (&src[threadIdx.x] != &cnt->pool_used) src[threadIdx.x] = 0u;
   }
+  if (threadIdx.x < kBandMax) { fb.gen_bands.cnt[threadIdx.x] = 0u; fb.unmark_bands.cnt[threadIdx.x] = 0u; }
   if (threadIdx.x == 0) fb.ticket[0] = 0u;
 }
 

@@ -50,6 +50,8 @@ struct MarkingState {
   uint32_t seq = 0;
   // fused route (marking_fused.hip.h)
   float4* unmark_pts = nullptr;            // [pool_cap]
+  float4* band_pts = nullptr;              // [2][kBandMax * kBandCap]: generator points of this update / of removed markings, by row of ground cells
+  uint32_t* band_cnt = nullptr;            // [2][kBandMax], all zero between updates
   uint32_t* clear_list = nullptr;          // [table]
   uint32_t* cell_count = nullptr;          // [kFuseMaxCells], all zero between updates
   bool alive_list_stale = false;           // the fused route keeps no alive list: the general route rebuilds it first
@@ -87,7 +89,7 @@ void marking_free(MarkingState* m) {
                m->gslot, m->parent, m->keys_a, m->keys_b, m->keys1, m->vals_a, m->vals_b, m->flags, m->incl, m->cid_incl, m->ds,
                m->proj, m->gen, m->ds_first, m->pool_ofs, m->compact_sizes, m->compact_ofs, m->cl.start, m->cl.size, m->cl.centroid,
                m->cl.state, m->cl.ds_count, m->cl.gen_first, m->cl.gen_count, m->cl.slot, m->cl.vkey, m->counters, m->n_groups,
-               m->temp, m->unmark_pts, m->ticket, m->clear_list, m->cell_count};
+               m->temp, m->unmark_pts, m->ticket, m->clear_list, m->cell_count, m->band_pts, m->band_cnt};
   for (void* q : p)
     if (q) (void)hipFree(q);
   if (m->host_out) (void)hipHostFree(m->host_out);
@@ -372,11 +374,14 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     HIPCHK(ctx, hipMalloc(&m->counters, sizeof(MarkCounters)));
     HIPCHK(ctx, hipMalloc(&m->n_groups, 2 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&m->unmark_pts, (size_t)m->pool_cap * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&m->band_pts, (size_t)2 * kBandMax * kBandCap * sizeof(float4)));
+    HIPCHK(ctx, hipMalloc(&m->band_cnt, (size_t)2 * kBandMax * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(m->band_cnt, 0, (size_t)2 * kBandMax * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&m->clear_list, (size_t)table * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&m->cell_count, (size_t)kFuseMaxCells * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(m->cell_count, 0, (size_t)kFuseMaxCells * sizeof(uint32_t)));
-    HIPCHK(ctx, hipMalloc(&m->ticket, 2 * sizeof(uint32_t)));
-    HIPCHK(ctx, hipMemset(m->ticket, 0, 2 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->ticket, 34 * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMemset(m->ticket, 0, 34 * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(m->counters, 0, sizeof(MarkCounters)));
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->host_out), sizeof(MarkCounters), hipHostMallocMapped));
     HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&m->host_out_dev), m->host_out, 0));
@@ -593,7 +598,7 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
     MarkCounters zero{};
     zero.pool_used = m->pool_used_host;
     HIPCHK(ctx, hipMemcpyAsync(m->counters, &zero, sizeof(zero), hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemsetAsync(m->ticket, 0, 2 * sizeof(uint32_t), st));
+    HIPCHK(ctx, hipMemsetAsync(m->ticket, 0, 34 * sizeof(uint32_t), st));
   }
   m->counters_clean = false;                 // (until this update's last block has run)
   if (timed) HIPCHK(ctx, hipEventRecord(m->e0, st));
@@ -606,10 +611,13 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   const PointGrid prev_grid = m->prev >= 0 ? m->obs[m->prev].g : empty_grid;
   if (mark) {
     float lo[3], hi[3];
-    obs_grid_shape(m, f, std::min(gb.cap_cells, kFuseMaxCells), gb.g, lo, hi);
+    uint32_t cap = std::min(gb.cap_cells, kFuseMaxCells);
+#ifdef DDDMR_PHASE_STAMPS
+    if (const char* e = std::getenv("DDDMR_MKF_CELLS")) cap = std::min<uint32_t>(cap, (uint32_t)std::atoi(e));
+#endif
+    obs_grid_shape(m, f, cap, gb.g, lo, hi);
     gb.g.n = n_obs;
   }
-  FuseBufs fb{obs, m->parent, m->ds, m->gen, m->clear_list, m->unmark_pts, m->ticket, m->cell_count, m->keys_a, m->host_out_dev};
   const uint32_t n_alive = m->n_alive_host;
   // ground cells of the window + inflation radius: the nodes the node-by-node dGraph updates look at
   SplatRange rg{};
@@ -622,8 +630,14 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
     rg.cy0 = host_cy(gg, lo[1] - pad); rg.cy1 = host_cy(gg, hi[1] + pad);
     rg.rows = (uint32_t)(rg.cy1 - rg.cy0 + 1) * (uint32_t)gg.nz;
     rg.segs = std::max(1u, (m->ground.max_row + 63u) / 64u);
+    rg.delta = (int)std::floor(((float)m->cfg.inflation_radius + 1e-3f) * gg.inv_xy) + 1;
+    rg.bands = (m->n_ground && (uint32_t)(rg.cy1 - rg.cy0 + 1) <= kBandMax) ? (uint32_t)(rg.cy1 - rg.cy0 + 1) : 0u;
   }
-  const uint32_t nb_items = m->n_ground ? (rg.rows * rg.segs + 3u) / 4u : 0u;
+  FuseBufs fb{obs, m->parent, m->ds, m->gen, m->clear_list, m->unmark_pts,
+              BandList{m->band_pts, m->band_cnt}, BandList{m->band_pts + (size_t)kBandMax * kBandCap, m->band_cnt + kBandMax}, rg,
+              m->ticket, m->cell_count, m->keys_a, m->host_out_dev};
+  const uint32_t seg_groups = (rg.segs + 3u) / 4u, n_part = 48u;
+  const uint32_t nb_band = rg.bands ? rg.rows * seg_groups * n_part : 0u;
   // 1: cell counts of the observation grid | every store slot: window + FOV test -> ray-test list
   const uint32_t nb_count = mark ? (n_obs + 255) / 256 : 0;
   MK_LAUNCH(m, k_mkf_pre, dim3(nb_count + (m->table + 255) / 256), dim3(256), 0, st, k, s, gb.g, fb, m->counters, nb_count);
@@ -636,15 +650,17 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   if (const char* e = std::getenv("DDDMR_MKF_EXP")) { if (std::atoi(e) & 1) nb_cc = 0; if (std::atoi(e) & 2) nb_clear = 0; }
 #endif
   if (nb_clear + nb_cc)
-    MK_LAUNCH(m, k_mkf_clear_cc, dim3(nb_clear + nb_cc), dim3(256), 0, st, k, s, prev_grid, gb.g, fb, m->counters, nb_clear);
+    MK_LAUNCH(m, k_mkf_clear_cc, dim3(nb_clear + nb_cc), dim3(256), 0, st, k, s, prev_grid, gb.g, m->ground.g, fb, m->counters, nb_clear);
   if (timed) HIPCHK(ctx, hipEventRecord(m->e1, st));
-  // 4: seeds | removePCPtr of the cleared markings (node by node; point by point outside the window's cells)
+  // 4: seeds | removePCPtr of the cleared markings: ground node by ground node, point by point for the points that found no band
   {
-    const uint32_t nb_roots = mark ? (n_obs + 255) / 256 : 0;
-    const uint32_t chunks = n_alive ? std::min<uint32_t>(16u, (m->pool_used_host + 255) / 256) : 0, nb_far = n_alive ? 64u : 0u;
-    if (nb_roots + nb_items * chunks + nb_far)
-      MK_LAUNCH(m, k_mkf_roots_unmark, dim3(nb_roots + nb_items * chunks + nb_far), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters,
-                rg, nb_roots, chunks ? nb_items : 0u, chunks);
+    uint32_t nb_roots = mark ? (n_obs + 255) / 256 : 0, nb_un = n_alive ? nb_band : 0u, nb_walk = n_alive ? 64u : 0u;
+#ifdef DDDMR_PHASE_STAMPS
+    if (const char* e = std::getenv("DDDMR_MKF_EXP")) { if (std::atoi(e) & 32) nb_un = 0; if (std::atoi(e) & 64) nb_walk = 0; }
+#endif
+    if (nb_roots + nb_un + nb_walk)
+      MK_LAUNCH(m, k_mkf_roots_unmark, dim3(nb_roots + nb_un + nb_walk), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters, nb_roots,
+                nb_un, seg_groups, n_part);
   }
   // 5: 64 partitions of the clusters
   if (mark)
@@ -652,10 +668,12 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
               m->counters);
   // 6: keepers -> pool | dGraph of the new generator points (node by node); the last block publishes the counters
   {
-    const uint32_t nb_commit = mark ? (n_obs + 255) / 256 : 0;
-    const uint32_t chunks = mark ? std::min<uint32_t>(24u, (n_obs + 255) / 256) : 0, nb_far = mark ? 64u : 1u;
-    MK_LAUNCH(m, k_mkf_commit_dgraph, dim3(nb_commit + nb_items * chunks + nb_far), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters,
-              rg, nb_commit, chunks ? nb_items : 0u, chunks);
+    uint32_t nb_commit = mark ? (n_obs + 255) / 256 : 0, nb_b = mark ? nb_band : 0u, nb_walk = mark ? 256u : 1u;
+#ifdef DDDMR_PHASE_STAMPS
+    if (const char* e = std::getenv("DDDMR_MKF_EXP")) { if (std::atoi(e) & 4) nb_commit = 0; if (std::atoi(e) & 8) nb_b = 0; if (std::atoi(e) & 16) nb_walk = 1; }
+#endif
+    MK_LAUNCH(m, k_mkf_commit_dgraph, dim3(nb_commit + nb_b + nb_walk), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters, nb_commit,
+              nb_b, seg_groups, n_part);
   }
   if (timed) HIPCHK(ctx, hipEventRecord(m->e2, st));
   HIPCHK(ctx, hipStreamSynchronize(st));
@@ -664,6 +682,7 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   m->counters_clean = true;
   m->alive_list_stale = true;
   ++m->updates_fused;
+  for (uint32_t v : out.n_cleared_shard) out.n_cleared += v;
   out.n_alive = n_alive - out.n_cleared + out.n_revived;
   out.n_clusters = n_obs;                                                        // extent of the per-cluster records (named by seed index)
   if (mark && !out.fallback) {
