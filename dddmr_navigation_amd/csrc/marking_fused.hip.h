@@ -7,9 +7,9 @@
 // tests, the hash insert -- runs in 64 independent 256-lane workgroups, each on the clusters whose seed point hashes
 // to it, with points, sort keys and payloads resident in LDS:
 //
-//   launch 1  k_mkf_pre             cell counts of the new observation's grid  |  every store slot: window + field-of-view
-//                                   test -> list of ray tests
-//   launch 2  k_mkf_grid            one workgroup: scan of the cell counts in LDS, scatter
+//   launch 1  k_mkf_count           cell counts of the new observation's grid
+//   launch 2  k_mkf_grid_fov        block 0: scan of the cell counts in LDS, scatter  |  every store slot: window +
+//                                   field-of-view test -> list of ray tests
 //   launch 3  k_mkf_clear_cc        selfClear ray tests (a wave per listed marking)  |  Euclidean clustering (union-find)
 //   launch 4  k_mkf_roots_unmark    every point's cluster seed (root of the union-find)  |  removePCPtr of the markings
 //                                   launch 3 cleared, ground node by ground node
@@ -217,26 +217,24 @@ __device__ __forceinline__ void fuse_grid_scan_scatter(const PointGrid& g, const
   MKF_STAMP(35);
 }
 
-// launch 2: one workgroup
-__global__ __launch_bounds__(1024) void k_mkf_grid(PointGrid obs, FuseBufs fb) {
+// launch 1: cell counts
+__global__ __launch_bounds__(256) void k_mkf_count(PointGrid obs, FuseBufs fb) { fuse_grid_count(obs, fb.pts, fb.parent, fb.cell_count, fb.slot); }
+
+// launch 2: block 0: scan + scatter of the observation grid (one workgroup)  |  blocks 1..: every slot of the store
+__global__ __launch_bounds__(1024) void k_mkf_grid_fov(MarkParams k, MarkStore s, PointGrid obs, FuseBufs fb, MarkCounters* __restrict__ cnt,
+                                                       uint32_t nb_grid) {
   __shared__ uint32_t cnt2[33 * 1024];
   __shared__ uint32_t wsum[16];
-  fuse_grid_scan_scatter(obs, fb.pts, fb.cell_count, fb.slot, cnt2, wsum);
-}
-
-__global__ __launch_bounds__(256) void k_mkf_pre(MarkParams k, MarkStore s, PointGrid obs, FuseBufs fb, MarkCounters* __restrict__ cnt,
-                                                 uint32_t nb_count) {
-  if (blockIdx.x < nb_count) {
-    fuse_grid_count(obs, fb.pts, fb.parent, fb.cell_count, fb.slot);
+  if (blockIdx.x < nb_grid) {
+    fuse_grid_scan_scatter(obs, fb.pts, fb.cell_count, fb.slot, cnt2, wsum);
     return;
   }
   // every slot of the store: no owner yet in this update; alive markings inside the window (integer test, one lane per
   // slot) are compacted in LDS, then the field-of-view test of k_mk_fov runs on the dense list (its double asin / atan2
-  // cost a wave as much as a lane: on the sparse slots 512 waves did the work of 128); those in view go on the
+  // cost a wave as much as a lane: on the sparse slots four times the waves did the same work); those in view go on the
   // ray-test list
-  __shared__ uint32_t lst[256];
-  __shared__ uint32_t wsum[4];
-  const uint32_t slot = (blockIdx.x - nb_count) * 256u + threadIdx.x;
+  uint32_t* lst = cnt2;
+  const uint32_t slot = (blockIdx.x - nb_grid) * 1024u + threadIdx.x;
   bool inwin = false;
   if (slot <= k.table_mask) {
     s.owner[slot] = 0ull;
@@ -248,7 +246,7 @@ __global__ __launch_bounds__(256) void k_mkf_pre(MarkParams k, MarkStore s, Poin
     }
   }
   uint32_t n_in;
-  const uint32_t at = block_excl_scan<4>(inwin ? 1u : 0u, wsum, &n_in);
+  const uint32_t at = block_excl_scan<16>(inwin ? 1u : 0u, wsum, &n_in);
   if (inwin) lst[at] = slot;
   __syncthreads();
   if (threadIdx.x == 0 && n_in) atomicAdd(&cnt->n_in_window, n_in);

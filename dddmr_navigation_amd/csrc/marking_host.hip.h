@@ -638,11 +638,13 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
               m->ticket, m->cell_count, m->keys_a, m->host_out_dev};
   const uint32_t seg_groups = (rg.segs + 3u) / 4u, n_part = 48u;
   const uint32_t nb_band = rg.bands ? rg.rows * seg_groups * n_part : 0u;
-  // 1: cell counts of the observation grid | every store slot: window + FOV test -> ray-test list
-  const uint32_t nb_count = mark ? (n_obs + 255) / 256 : 0;
-  MK_LAUNCH(m, k_mkf_pre, dim3(nb_count + (m->table + 255) / 256), dim3(256), 0, st, k, s, gb.g, fb, m->counters, nb_count);
-  // 2: scan + scatter of the observation grid
-  if (mark) MK_LAUNCH(m, k_mkf_grid, dim3(1), dim3(1024), 0, st, gb.g, fb);
+  // 1: cell counts of the observation grid
+  if (mark) MK_LAUNCH(m, k_mkf_count, dim3((n_obs + 255) / 256), dim3(256), 0, st, gb.g, fb);
+  // 2: scan + scatter of the observation grid (one workgroup) | every store slot: window + FOV test -> ray-test list
+  {
+    const uint32_t nb_grid = mark ? 1u : 0u;
+    MK_LAUNCH(m, k_mkf_grid_fov, dim3(nb_grid + (m->table + 1023) / 1024), dim3(1024), 0, st, k, s, gb.g, fb, m->counters, nb_grid);
+  }
   // 3: ray tests | union-find
   uint32_t nb_clear = (n_alive + 3) / 4, nb_cc = mark ? (n_obs * 4 + 255) / 256 : 0;
 #ifdef DDDMR_PHASE_STAMPS
