@@ -35,8 +35,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed ticks (default 1000; 400 for C3/C4 on one GPU)")
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5", "C5M"],
-                    help="default: C3 on one GPU, C4 (strong scaling) on several")
+    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5", "C5M", "shipped"],
+                    help="default: C3 on one GPU, C4 (strong scaling) on several; shipped = only the tick latencies of the "
+                         "reference's shipped configurations (55 / 275 / 2 trajectories)")
+    ap.add_argument("--inputs", default="static", choices=["static", "moving"],
+                    help="static (default, the headline): every tick sees the same pose / twist / cloud; moving: the robot "
+                         "advances along the prune plan every tick and the cloud is replaced every --replace-every ticks "
+                         "(always measured as config.moving_value on one GPU; --inputs moving makes it the headline value)")
+    ap.add_argument("--replace-every", type=int, default=10)
+    ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / moving / shipped-latency measurements")
     ap.add_argument("--scene-layout", default=None, choices=["r02", "r01"],
                     help="r02 (default): ~25 %% colliding trajectories as SURVEY 8d specifies; r01: the round-1 scenes (69-86 %%)")
     ap.add_argument("--backend", default=os.environ.get("DDDMR_BENCH_BACKEND", "nccl"),
@@ -89,6 +96,57 @@ def self_launch(args):
 def median(xs):
     xs = sorted(xs)
     return xs[len(xs) // 2] if xs else 0.0
+
+
+def moving_inputs(scenes, sc, n_ticks):
+    """Pose / twist per tick for --inputs moving: the robot follows the prune plan (one 5 cm pose every two ticks,
+    20 ... 60 of its 80 poses, then back), its twist wanders inside the dynamic window, and two variants of the
+    cloud alternate (the second with every 16th point displaced by a few centimetres, as a new scan would)."""
+    import math
+    import numpy as np
+    ticks = []
+    for k in range(n_ticks):
+        i = 20 + ((k // 2) % 40)
+        pose = tuple(sc.plan[i])
+        twist = (0.5 + 0.15 * math.sin(k / 7.0), 0.05 * math.sin(k / 3.0), 0.25 * math.sin(k / 5.0))
+        ticks.append(scenes.tick_input(pose=pose, twist=twist))
+    rng = np.random.default_rng(1234)
+    alt = sc.cloud.copy()
+    alt[::16, :3] += rng.uniform(-0.03, 0.03, size=alt[::16, :3].shape).astype(np.float32)
+    return ticks, [sc.cloud, alt]
+
+
+def shipped_latencies(np, scenes, configs, LocalPlanner, gpu):
+    """Tick latency (host wall time of dddmr_rollout_tick, result delivered) of the configurations the reference ships,
+    against the C1 cloud: warm = back to back, cold = after 100 ms of idling (a 10 Hz control loop)."""
+    c1 = scenes.bench_scene("C1")
+    pg = scenes.playground_scene()
+    cases = [("playground differential_drive_simple (55 trajectories x 21-61 steps)", pg.theory, pg.plan, pg.tick),
+             ("omni_drive_simple 5 x 5 x 11 (275)", configs.omni_simple_shipped(), c1.plan, scenes.tick_input(twist=(0.3, 0.0, 0.0))),
+             ("differential_drive_rotate_inplace (2 x 126 steps)", configs.rotate_inplace_shipped(), c1.plan, scenes.tick_input(twist=(0.0, 0.0, 0.0)))]
+    out = []
+    for label, th, plan, tick in cases:
+        with LocalPlanner([th], device=gpu, max_points=len(c1.cloud)) as lp:
+            lp.set_cloud(c1.cloud)
+            lp.setPlan(plan)
+            name = th.name.decode()
+            for _ in range(20):
+                r = lp.tick(name, tick)
+            warm = []
+            for _ in range(200):
+                t0 = time.perf_counter()
+                r = lp.tick(name, tick)
+                warm.append(time.perf_counter() - t0)
+            cold = []
+            for _ in range(12):
+                time.sleep(0.1)
+                t0 = time.perf_counter()
+                r = lp.tick(name, tick)
+                cold.append(time.perf_counter() - t0)
+            out.append({"theory": label, "n_trajectories": int(r.n_samples), "planner_state": int(r.planner_state),
+                        "warm_tick_ms": round(median(warm) * 1e3, 4), "cold_tick_ms": round(median(cold) * 1e3, 4),
+                        "cold_tick_ms_max": round(max(cold) * 1e3, 4)})
+    return out
 
 
 def main():
@@ -151,6 +209,20 @@ def main():
 
     # ---- workload ----
     workload = args.workload or ("C3" if world == 1 else "C4")
+    if workload == "shipped":
+        if world > 1:
+            raise SystemExit("--workload shipped is a single-GPU latency measurement")
+        sh = shipped_latencies(np, scenes, configs, LocalPlanner, gpu)
+        n0, t0 = sh[0]["n_trajectories"], sh[0]["warm_tick_ms"]
+        json_out.write(json.dumps({
+            "metric": "scored trajectories/sec (N_traj x N_steps)", "value": round(n0 / (t0 * 1e-3), 1), "unit": "trajectories/s",
+            "n_gpus": 1, "steps": 200, "warmup": 20, "ms_per_step": t0, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "shipped: tick latency of the reference's shipped theories against the 5000-point C1 cloud "
+                                   "(value = the playground theory's warm rate)", "shipped_tick_latency": sh},
+            "roofline": None, "cpu_baseline": None}) + "\n")
+        json_out.flush()
+        return
     layout = args.scene_layout or scenes.DEFAULT_LAYOUT
     feed = workload in ("C5", "C5M")
     base = "C2" if feed else workload
@@ -373,6 +445,76 @@ def main():
         ceiling = {"copy_GBps": round(cp, 1), "read_GBps": round(rd, 1), "buffer_bytes": 1 << 30,
                    "note": "float4 grid-stride kernels of this library on this GPU (copy counts read + write bytes)"}
 
+    # ---- what a control loop sees (one GPU, resident-cloud workloads): inputs that move, the host boundary, the shipped sizes ----
+    extras = {}
+    if rank == 0 and world == 1 and scans is None and len(lps) == 1 and not args.no_extras:
+        import oracle as _oracle
+        # (a) moving inputs: pose / twist advance along the prune plan every tick, the cloud is replaced every k ticks
+        #     (set_cloud of the other variant, H2D included); the last tick is checked against the oracle
+        n_mv = max(60, min(args.steps, 200))
+        mv_ticks, mv_clouds = moving_inputs(scenes, sc, n_mv + 10)
+        for k in range(10):
+            lp.tick(name, mv_ticks[k])
+        torch.cuda.synchronize()
+        t_ticks, n_sum, which = 0.0, 0, 0
+        t0 = time.perf_counter()
+        for k in range(10, n_mv + 10):
+            if (k - 10) % args.replace_every == 0 and k > 10:
+                which ^= 1
+                lp.set_cloud(mv_clouds[which])
+            t1 = time.perf_counter()
+            mv_res = lp.tick(name, mv_ticks[k])
+            t_ticks += time.perf_counter() - t1
+            n_sum += int(mv_res.n_samples)
+        t_mv = time.perf_counter() - t0
+        mo = _oracle.tick(theory, mv_clouds[which], sc.plan, mv_ticks[n_mv + 9], n_threads=os.cpu_count() or 1).result
+        mv_ok = bool(mv_res.planner_state == mo.planner_state and int(mv_res.best_index) == int(mo.best_index) and
+                     abs(mv_res.vx - mo.vx) <= 1e-4 and abs(mv_res.vy - mo.vy) <= 1e-4 and abs(mv_res.wz - mo.wz) <= 1e-4 and
+                     (mv_res.best_index < 0 or abs(mv_res.best_cost - mo.best_cost) <= 1e-4))
+        extras["moving"] = {
+            "value": round(n_sum / t_mv, 1), "ticks_only_value": round(n_sum / t_ticks, 1), "unit": "trajectories/s",
+            "ticks": n_mv, "ms_per_tick": round(t_mv / n_mv * 1e3, 5), "ms_per_tick_ticks_only": round(t_ticks / n_mv * 1e3, 5),
+            "mean_trajectories_per_tick": round(n_sum / n_mv, 1), "cloud_replaced_every": args.replace_every,
+            "last_tick_matches_oracle": mv_ok, "last_tick_best_index": int(mv_res.best_index), "oracle_best_index": int(mo.best_index),
+            "note": "pose / twist advance along the prune plan every tick; set_cloud (H2D of the other cloud variant) every "
+                    f"{args.replace_every} ticks is inside `value`, outside `ticks_only_value`"}
+        lp.set_cloud(sc.cloud)
+        # (b) end to end through the host boundary: the reference re-aggregates the cloud every tick
+        #     (local_planner.cpp:498-511), so: set_cloud from pageable 32-byte pcl::PointXYZI records + tick + result
+        xyzi32 = np.zeros((len(sc.cloud), 8), np.float32)
+        xyzi32[:, :4] = sc.cloud
+        for _ in range(3):
+            lp.set_cloud(xyzi32); lp.tick(name, sc.tick)
+        n_e2e = 30
+        t_set = 0.0
+        t0 = time.perf_counter()
+        for _ in range(n_e2e):
+            t1 = time.perf_counter()
+            lp.set_cloud(xyzi32)
+            t_set += time.perf_counter() - t1
+            e_res = lp.tick(name, sc.tick)
+        t_e2e = (time.perf_counter() - t0) / n_e2e
+        extras["end_to_end"] = {
+            "ms": round(t_e2e * 1e3, 5), "value": round(int(e_res.n_samples) / t_e2e, 1), "unit": "trajectories/s",
+            "set_cloud_ms": round(t_set / n_e2e * 1e3, 5), "cloud_bytes": int(xyzi32.nbytes),
+            "what": "set_cloud from pageable host memory, 32-byte pcl::PointXYZI records (repack + H2D) + tick + result on the host, every tick"}
+        lp.set_cloud(sc.cloud)
+        lp.tick(name, sc.tick)
+        # (c) the sizes the reference ships (55 / 275 / 2 x 126), warm and after 100 ms of idling
+        extras["shipped_tick_latency"] = shipped_latencies(np, scenes, configs, LocalPlanner, gpu)
+
+    rank_info = None
+    if world > 1:
+        pr = torch.cuda.get_device_properties(gpu)
+        mine = {"rank": rank, "device": gpu, "name": pr.name,
+                "pci": f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', -1):02x}:{getattr(pr, 'pci_device_id', -1):02x}",
+                "uuid": str(getattr(pr, "uuid", ""))}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        rank_info = gathered
+        if rank == 0 and args.backend == "nccl" and len({g["pci"] for g in gathered}) != world:
+            print(f"[bench] WARNING: {world} ranks on fewer distinct GPUs: {[g['pci'] for g in gathered]}", file=sys.stderr, flush=True)
+
     out = None
     if rank == 0:
         import oracle
@@ -386,9 +528,11 @@ def main():
         same_index = int(res.best_index) == int(rf.best_index)
         near_tie = (not same_index and res.best_index >= 0 and rf.best_index >= 0 and
                     abs(res.best_cost - rf.best_cost) <= 1e-6)
-        parity_ok = bool(res.planner_state == rf.planner_state and (same_index or near_tie) and
-                         (not same_index or (abs(res.vx - rf.vx) <= 1e-4 and abs(res.vy - rf.vy) <= 1e-4 and
-                                             abs(res.wz - rf.wz) <= 1e-4 and abs(res.best_cost - rf.best_cost) <= 1e-4)))
+        # strict: the same winner AND its command / cost within 1e-4 (a near-tie that picked another index is reported
+        # by winner_near_tie_within_1e-6 alone, never as a match)
+        parity_ok = bool(res.planner_state == rf.planner_state and same_index and
+                         abs(res.vx - rf.vx) <= 1e-4 and abs(res.vy - rf.vy) <= 1e-4 and abs(res.wz - rf.wz) <= 1e-4 and
+                         (res.best_index < 0 or abs(res.best_cost - rf.best_cost) <= 1e-4))
         # ---- roofline of the dominant kernel (k_score) ----
         # (a) HBM roofline with the bytes THIS kernel must move once (compulsory traffic): the
         #     rollout state it reads (24 B per trajectory-step), the cell-sorted tile points (12 B),
@@ -402,7 +546,7 @@ def main():
         units = int(r.steps_total)                         # trajectory-steps per launch (rank 0's shard)
         n_tile = int(lp.last_result.n_points_binned)
         compulsory = 24 * units + 12 * n_tile + 4 * 4096 + 64 * n_local + 16 * len(sc.plan)
-        ref_bytes = 32 * int(r.steps_eval) + 16 * int(r.k_sum) + 32 * len(sc.plan) + 32 * n_local
+        ref_bytes = 32 * int(r.steps_eval) + 16 * int(r.k_sum) + 16 * len(ocloud) + 32 * len(sc.plan) + 32 * n_local   # SURVEY 8d B_alg, 16 P included
         k_ms = float(np.mean(score_ms)) if score_ms else float("nan")
         t_ms = float(np.mean(dev_ms)) if dev_ms else float("nan")
         achieved = compulsory / (k_ms * 1e-3) / 1e9
@@ -420,15 +564,23 @@ def main():
             "bound": "hbm", "kernel": "k_score",
             "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
             "traffic": traffic,
+            "traffic_static": {"static": True, "source": "profiles/traffic.json (PMC passes of an earlier run of this workload, not this run)"},
+            # SURVEY 8d's own fraction: B_alg (what the reference's radius searches gather: 32 B per evaluated step + 16 B per
+            # neighbour + 16 P + 32 M + 32 N) over the tick / the kernel, / 8 TB/s.  A work rate against the HBM peak: this
+            # design never moves those bytes (frac above is the physical one).
+            "frac_alg_tick": round(ref_bytes / (elapsed / args.steps) / 8.0e12, 4),
+            "frac_alg_kernel": round(ref_bytes / (k_ms * 1e-3) / 8.0e12, 4) if k_ms == k_ms else None,
+            "b_alg_bytes": ref_bytes,
             "bytes_per_launch": compulsory, "units_per_launch": units,
             "bytes_per_unit": round(compulsory / max(units, 1), 2),
             "kernel_ms": round(k_ms, 5), "kernel_ms_rocprofv3": prof.get("r02_kernel_avg.json", {}).get("k_score_ms"),
+            "kernel_ms_rocprofv3_static": True,
             "tick_device_ms": round(t_ms, 5),
             "what_binds_it": {
                 "name": "VALU issue + memory/LDS latency (not HBM: the working set is L2/MALL resident)",
                 "valu_busy_frac_of_issue_cycles": pmc.get("valu_busy_frac"),
                 "waves_waiting_frac": pmc.get("waves_waiting_frac"),
-                "source": "profiles/r02_pmc.json" if pmc else None},
+                "static": True, "source": "profiles/r02_pmc.json (an earlier run, not this one)" if pmc else None},
             "stream_ceiling": ceiling,
             "frac_of_copy_ceiling": round(achieved / ceiling["copy_GBps"], 4) if ceiling else None,
             "reference_equivalent_gather": {
@@ -466,6 +618,36 @@ def main():
                    "rollout_ms": round(median(gen) * 1e3, 2), "scoring_ms": round(median(scr) * 1e3, 2),
                    "all_cores_value": round(n_global / median(alls), 1), "all_cores": ncpu,
                    "all_cores_note": "rollout + scoring threaded over trajectories, kd-tree build serial"}
+        if world == 1 and not args.no_cpu_baseline and scans is not None:
+            # C5 / C5M: the oracle's whole step on ONE core -- cbSensor feed (crop + VoxelGrid) + [selfClear / selfMark of the
+            # marking layer] + the C2 tick on the resulting cloud -- over the same scans, a bounded sample
+            mo = None
+            if marking is not None:
+                from dddmr_navigation_amd import marking as marking_mod
+                walls = sc.cloud[(np.abs(np.abs(sc.cloud[:, 1]) - 9.9) < 0.05)]
+                mo = oracle.MarkingOracle(marking_mod.shipped_config(perception_window_size=10.0), marking_mod.ground_lattice(), walls[:, :3])
+            steps_cpu, t_feed, t_mark, t_tick, t_cpu, i = [], [], [], [], 0.0, 0
+            while (t_cpu < args.cpu_seconds and len(steps_cpu) < 20) or len(steps_cpu) < 3:
+                scan = scans[i % len(scans)]
+                i += 1
+                t1 = time.perf_counter()
+                obs_cpu = oracle.feed(scan[:, :3], t_bs, t_gb, 10.0, 2.0)
+                t2 = time.perf_counter()
+                if mo is not None:
+                    mo.update(obs_cpu[:, :3], t_bs, t_gb)
+                t3 = time.perf_counter()
+                oracle.tick(theory, obs_cpu, sc.plan, sc.tick, n_threads=1)
+                t4 = time.perf_counter()
+                if i > 1:                      # (the first step warms caches and fills the marking store)
+                    steps_cpu.append(t4 - t1); t_feed.append(t2 - t1); t_mark.append(t3 - t2); t_tick.append(t4 - t3)
+                t_cpu += t4 - t1
+            cpu = {"value": round(n_global / median(steps_cpu), 1), "unit": "trajectories/s", "cores": 1, "kind": "port",
+                   "sample": f"median of {len(steps_cpu)} {workload} steps (feed of a 16x1800 scan"
+                             + (" + marking / clearing update" if mo is not None else "") + f" + C2 tick of {n_global} trajectories) "
+                             f"after one warm-up step, {t_cpu:.1f} s of CPU; oracle built -O3 -march=x86-64-v3",
+                   "step_ms": round(median(steps_cpu) * 1e3, 2), "feed_ms": round(median(t_feed) * 1e3, 2),
+                   "marking_update_ms": round(median(t_mark) * 1e3, 2) if mo is not None else None,
+                   "tick_ms": round(median(t_tick) * 1e3, 2)}
         colliding = float((ofull.costs == -1.0).mean())
         out = {
             "metric": "scored trajectories/sec (N_traj x N_steps)", "value": round(value, 1),
@@ -492,7 +674,33 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if marking is not None:
-            out["config"]["marking"] = marking.summary()
+            ms = marking.summary()
+            out["config"]["marking"] = ms
+            # the marking / clearing update against the HBM roofline: bytes it must move once (observation read by the grid
+            # count, the scatter, the union-find and the partitions, 16 B each; grid cells; the store's slots; generator
+            # points out and in; the window's ground nodes with their dGraph / lethal entries) over its HIP-event time.
+            n_obs = len(ocloud)
+            upd_ms = ms["clear_ms"] + ms["mark_ms"]
+            b_upd = (4 * 16 + 8 + 4) * n_obs + 2 * 4 * 65536 + 32 * ms["alive_markings"] + 2 * 32 * int(ms["marked_per_update"] * 1.3) + 25 * 8000
+            out["roofline_marking"] = {
+                "bound": "hbm", "kernel": "marking update (6 launches: k_mkf_*)", "achieved": round(b_upd / (upd_ms * 1e-3) / 1e9, 2) if upd_ms > 0 else None,
+                "peak": 8000.0, "unit": "GB/s", "frac": round(b_upd / (upd_ms * 1e-3) / 8.0e12, 5) if upd_ms > 0 else None,
+                "bytes_per_update": b_upd, "update_ms": round(upd_ms, 5), "traffic": None,
+                "what_binds_it": {"name": "dependent-latency chains and instruction issue (ray marches, union-find, 64 one-workgroup partitions), "
+                                          "not HBM: the update's working set is a few MB", "static": True,
+                                  "source": "profiles/r03_C5M_fused_pmc.json, profiles/r03_C5M_fused_kernel_stats.csv"}}
+        out.update(extras)
+        if "moving" in extras:
+            out["config"]["moving_value"] = extras["moving"]["value"]
+            if args.inputs == "moving":
+                out["config"]["static_value"] = out["value"]
+                out["value"] = extras["moving"]["value"]
+                out["ms_per_step"] = extras["moving"]["ms_per_tick"]
+                out["config"]["inputs"] = "moving (value = the moving-input rate; static_value = identical ticks)"
+        if world > 1:
+            out["config"]["ranks_seen"] = {"torch_world_size": dist.get_world_size(), "backend": args.backend, "ranks": rank_info,
+                                           "distinct_gpus": len({g["pci"] for g in rank_info}),
+                                           "inlib_communicator_ranks": lp.comm_ranks() if reduce_mode == "inlib" else None}
 
     # ---- the in-library RCCL exchange, measured after the timed loop (`--reduce auto`, RCCL backend) ----
     # k_score -> ncclAllReduce(min) -> k_resolve on the tick's stream: the synchronous tick a C++ host gets without
@@ -504,11 +712,15 @@ def main():
 
         def watchdog():
             if not done.wait(90.0):
+                # a collective that never returns: the line gathered so far is printed (marked failed), then EVERY rank
+                # leaves with a non-zero code -- a hung GPU exchange is a failure of the run, not a footnote
+                print(f"[bench] rank {rank}: in-library RCCL exchange did not return within 90 s", file=sys.stderr, flush=True)
                 if out is not None:
-                    out["config"]["inlib_rccl"] = {"status": "timed out after 90 s"}
+                    out["config"]["inlib_rccl"] = {"status": "FAILED: timed out after 90 s"}
+                    out["failed"] = "in-library RCCL exchange hung"
                     json_out.write(json.dumps(out) + "\n")
                     json_out.flush()
-                os._exit(0)
+                os._exit(3)
         threading.Thread(target=watchdog, daemon=True).start()
         inlib = {"status": "communicator did not come up on every rank"}
         try:
@@ -522,7 +734,7 @@ def main():
                     lat.append((time.perf_counter() - t1) * 1e3)
                 lt = torch.tensor([median(lat[10:])], dtype=torch.float64, device=red_dev)
                 dist.all_reduce(lt, op=dist.ReduceOp.MAX)
-                inlib = {"status": "ok", "sync_tick_ms": round(float(lt.item()), 5),
+                inlib = {"status": "ok", "communicator_ranks": lp.comm_ranks(), "sync_tick_ms": round(float(lt.item()), 5),
                          "trajectories_per_s_synchronous": round(n_global / (float(lt.item()) * 1e-3), 1),
                          "winner_equals_torch_path": bool(r2.best_index == res.best_index and r2.best_cost == res.best_cost),
                          "note": "k_score -> ncclAllReduce(ncclInt64, ncclMin) of the slot vector -> k_resolve on the context's stream"}
