@@ -8,6 +8,8 @@
 #ifndef DDDMR_ROLLOUT_ADAPTER_THEORY_CONFIG_FROM_PARAMS_H_
 #define DDDMR_ROLLOUT_ADAPTER_THEORY_CONFIG_FROM_PARAMS_H_
 
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <stdexcept>
@@ -107,6 +109,30 @@ inline void appendCritics(rclcpp::Node & critics, std::vector<dddmr_theory_confi
   }
 }
 
+// Capacities of the context, derived from what the YAML can make a tick ask for (a theory's sample grid, its longest
+// horizon) instead of literals; every one can be overridden on the generators node ("gpu_rollout.max_points" ...).
+// max_points has no counterpart in the reference's parameters (the aggregate observation is as large as the sensors make
+// it): default 2^20 - 1, the library's limit; a larger cloud makes the tick fail loudly (PERCEPTION_MALFUNCTION in
+// the patched planner), never plan against an older one.
+inline void sizeContext(rclcpp::Node & generators, const std::vector<dddmr_theory_config> & theories, dddmr_rollout_config & cfg)
+{
+  double samples = 64.0, steps = 32.0;
+  for (const auto & t : theories) {
+    const double nx = std::max(2.0, t.linear_x_sample) + 1.0, ny = std::max(2.0, t.linear_y_sample) + 1.0;   // (+1: the inserted zero)
+    const double nth = std::max(2.0, t.angular_z_sample) + 1.0;
+    samples = std::max(samples, t.kind == DDDMR_THEORY_OMNI_SIMPLE ? nx * ny * nth : (t.kind == DDDMR_THEORY_DD_SIMPLE ? nx * nth : 2.0));
+    const double vmax = std::max({std::fabs(t.max_vel_x), std::fabs(t.min_vel_x), std::fabs(t.max_vel_y), std::fabs(t.max_vel_trans)});
+    double s = std::max(vmax * t.sim_time / std::max(t.sim_granularity, 1e-3), std::fabs(t.max_vel_theta) * t.sim_time / std::max(t.angular_sim_granularity, 1e-3));
+    if (t.kind == DDDMR_THEORY_DD_ROTATE_INPLACE) {s = 6.28 / std::max(t.angular_sim_granularity, 1e-3);}
+    steps = std::max(steps, std::ceil(s) + 2.0);
+  }
+  cfg.max_trajectories = static_cast<uint32_t>(readParam<int>(generators, "gpu_rollout.max_trajectories", static_cast<int>(std::min(samples * 1.25, 1048576.0))));
+  cfg.max_steps = static_cast<uint32_t>(readParam<int>(generators, "gpu_rollout.max_steps", static_cast<int>(std::min(steps, 700.0))));
+  cfg.max_plan_poses = static_cast<uint32_t>(readParam<int>(generators, "gpu_rollout.max_plan_poses", 512));
+  cfg.max_points = static_cast<uint32_t>(readParam<int>(generators, "gpu_rollout.max_points", (1 << 20) - 1));
+  cfg.device = readParam<int>(generators, "gpu_rollout.device", cfg.device);
+}
+
 // One context for all theories of the generators node with the critic stacks of the critics node.
 inline dddmr_rollout_ctx * createContextFromNodes(rclcpp::Node & generators, rclcpp::Node & critics, int device = 0)
 {
@@ -119,10 +145,7 @@ inline dddmr_rollout_ctx * createContextFromNodes(rclcpp::Node & generators, rcl
   cfg.abi_version = DDDMR_ROLLOUT_ABI_VERSION;
   cfg.device = device;
   cfg.world_size = 1;
-  cfg.max_points = 600000;
-  cfg.max_trajectories = 1u << 16;
-  cfg.max_steps = 512;
-  cfg.max_plan_poses = 512;
+  sizeContext(generators, theories, cfg);
   cfg.n_theories = static_cast<int32_t>(theories.size());
   cfg.theories = theories.data();
   dddmr_rollout_ctx * ctx = nullptr;

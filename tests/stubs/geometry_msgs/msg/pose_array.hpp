@@ -1,0 +1,3 @@
+// stand-in for <geometry_msgs/msg/pose_array.hpp>: see tests/stubs/README.md
+#pragma once
+#include "ros_stub_all.hpp"

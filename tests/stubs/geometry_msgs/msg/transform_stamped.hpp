@@ -1,0 +1,3 @@
+// stand-in for <geometry_msgs/msg/transform_stamped.hpp>: see tests/stubs/README.md
+#pragma once
+#include "ros_stub_all.hpp"

@@ -1,0 +1,3 @@
+// stand-in for <tf2/impl/utils.h>: see tests/stubs/README.md
+#pragma once
+#include "ros_stub_all.hpp"

@@ -1,0 +1,3 @@
+// stand-in for <visualization_msgs/msg/marker_array.hpp>: see tests/stubs/README.md
+#pragma once
+#include "ros_stub_all.hpp"
