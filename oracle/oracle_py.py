@@ -35,7 +35,7 @@ def load(build_if_missing: bool = True) -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.join(_HERE, "liboracle.so")
+    path = os.path.join(_HERE, os.environ.get("DDDMR_ORACLE_LIB", "liboracle.so"))     # (liboracle_asan.so: `make -C oracle asan`)
     if not os.path.exists(path):
         if not build_if_missing:
             raise RuntimeError(f"{path} missing; run `make -C oracle`")
