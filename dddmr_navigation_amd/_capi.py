@@ -208,6 +208,8 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_marking_get_dgraph",
     "dddmr_rollout_marking_get_lethal",
     "dddmr_rollout_marking_route_counts",
+    "dddmr_rollout_set_scan_source",
+    "dddmr_rollout_set_stitcher_source",
     "dddmr_rollout_stream_ceiling",
     "dddmr_rollout_selftest_sincos",
     "dddmr_rollout_last_error",
@@ -309,6 +311,11 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_marking_get_lethal.restype = C.c_int
     lib.dddmr_rollout_marking_route_counts.argtypes = [ctx_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     lib.dddmr_rollout_marking_route_counts.restype = C.c_int
+    lib.dddmr_rollout_set_scan_source.argtypes = [ctx_p, C.c_int32, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_double),
+                                                  C.POINTER(C.c_double), C.c_double, C.c_double, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    lib.dddmr_rollout_set_scan_source.restype = C.c_int
+    lib.dddmr_rollout_set_stitcher_source.argtypes = [ctx_p, C.c_int32, C.c_int32]
+    lib.dddmr_rollout_set_stitcher_source.restype = C.c_int
     lib.dddmr_rollout_stream_ceiling.argtypes = [ctx_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.dddmr_rollout_stream_ceiling.restype = C.c_int
     lib.dddmr_rollout_selftest_sincos.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]

@@ -207,6 +207,13 @@ struct dddmr_rollout_ctx {
   double* poses_dev = nullptr;
   // perception feed scratch
   PerceptionScratch feed{};
+  // several sensors feeding one aggregate (StackedPerception::aggregateObservations, stacked_perception.cpp:128-140):
+  // sources 1.. get their own scratch (stitcher state, staging) and every source its latest observation on the device
+  static constexpr int kMaxSources = DDDMR_MAX_SOURCES;
+  PerceptionScratch* src_feed[kMaxSources] = {};       // [0] unused (source 0 feeds through `feed`)
+  float4* src_cloud[kMaxSources] = {};                 // latest observation of a source, allocated on first use
+  uint32_t src_n[kMaxSources] = {};
+  bool multi_source = false;
 
   // pinned host memory
   float4* cloud_stage[kCloudBufs] = {nullptr, nullptr, nullptr};   // pinned staging, one per device cloud buffer
@@ -252,6 +259,7 @@ struct dddmr_rollout_ctx {
   int rt_override = 0;        // DDDMR_RT: trajectories per rollout workgroup
   int threads_override = 0;   // DDDMR_THREADS: force the 256- or 512-lane k_score
   int n_cu = 256;   // compute units of the device
+  bool tail_round = false;      // DDDMR_TAIL_ROUND=1: one last round of short k_score workgroups (measured: C3 +3 us, C4 -7 us; off)
   int timing = 1;   // DDDMR_TIMING: 0 no HIP events, 1 around k_score (score_ms), 2 also around the whole tick
   int timing_every = 1;   // DDDMR_TIMING_EVERY: record the events on every n-th tick only
   int spin = 1;     // DDDMR_SPIN: poll the host-mapped result instead of hipStreamSynchronize
@@ -490,6 +498,10 @@ void dddmr_rollout_destroy(dddmr_rollout_ctx* ctx) {
   for (void* p : dev)
     if (p) (void)hipFree(p);
   perception_free(ctx->feed);
+  for (int i = 0; i < dddmr_rollout_ctx::kMaxSources; ++i) {
+    if (ctx->src_feed[i]) { perception_free(*ctx->src_feed[i]); delete ctx->src_feed[i]; }
+    if (ctx->src_cloud[i]) (void)hipFree(ctx->src_cloud[i]);
+  }
   for (int i = 0; i < kCloudBufs; ++i)
     if (ctx->cloud_stage[i]) (void)hipHostFree(ctx->cloud_stage[i]);
   if (ctx->small_stage) (void)hipHostFree(ctx->small_stage);
@@ -537,6 +549,7 @@ int dddmr_rollout_create(const dddmr_rollout_config* cfg, dddmr_rollout_ctx** ou
   if (const char* e = std::getenv("DDDMR_TILE")) ctx->tile_override = std::atoi(e);
   if (const char* e = std::getenv("DDDMR_RT")) ctx->rt_override = std::atoi(e);
   if (const char* e = std::getenv("DDDMR_THREADS")) ctx->threads_override = std::atoi(e) == 512 ? 512 : 256;
+  if (const char* e = std::getenv("DDDMR_TAIL_ROUND")) ctx->tail_round = std::atoi(e) != 0;
   if (const char* e = std::getenv("DDDMR_TIMING")) ctx->timing = std::atoi(e);
   if (const char* e = std::getenv("DDDMR_TIMING_EVERY")) ctx->timing_every = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("DDDMR_SPIN")) ctx->spin = std::atoi(e);
@@ -691,18 +704,33 @@ int dddmr_rollout_set_cloud(dddmr_rollout_ctx* ctx, const float* xyzi, size_t n_
   return DDDMR_OK;
 }
 
-int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_points,
-                           size_t stride_bytes, const double T_base_sensor[7],
-                           const double T_gbl_base[7], double perception_window_size,
-                           double marking_height, uint32_t* n_out_points) {
+// one sensor's scan through the feed; source < 0: the single-producer form (the result replaces the aggregate)
+static int set_scan_impl(dddmr_rollout_ctx* ctx, int source, const float* xyz, size_t n_points, size_t stride_bytes,
+                         const double T_base_sensor[7], const double T_gbl_base[7], double perception_window_size,
+                         double marking_height, uint32_t* n_out_points, uint32_t* n_aggregate) {
   if (!ctx || !T_base_sensor || !T_gbl_base) return DDDMR_ERR_BAD_ARG;
+  if (source >= dddmr_rollout_ctx::kMaxSources) return fail(ctx, DDDMR_ERR_BAD_ARG, "set_scan: source %d (at most %d sensors)", source, dddmr_rollout_ctx::kMaxSources);
   if (n_points > 0 && (!xyz || stride_bytes < 12 || stride_bytes % 4 != 0))
     return fail(ctx, DDDMR_ERR_BAD_ARG, "set_scan: bad pointer/stride");
   if (n_points > ctx->cfg.max_points)
     return fail(ctx, DDDMR_ERR_CAPACITY, "set_scan: %zu points > max_points %u", n_points, ctx->cfg.max_points);
-  if (ctx->feed.stitcher_num > 0 && n_points == 0) return fail(ctx, DDDMR_ERR_BAD_ARG, "set_scan: empty scan with the stitcher on");
   HIPCHK(ctx, hipSetDevice(ctx->device));
   std::lock_guard<std::mutex> prod(ctx->producer_mu);
+  if (source < 0 && ctx->multi_source) source = 0;              // once several sensors feed, plain set_scan is sensor 0
+  PerceptionScratch* scratch = &ctx->feed;
+  if (source > 0) {
+    if (!ctx->src_feed[source]) {
+      auto* ps = new PerceptionScratch();
+      if (perception_alloc(*ps, ctx->cfg.max_points) != 0) { perception_free(*ps); delete ps; return fail(ctx, DDDMR_ERR_HIP, "set_scan: scratch of source %d", source); }
+      ctx->src_feed[source] = ps;
+    }
+    scratch = ctx->src_feed[source];
+  }
+  if (scratch->stitcher_num > 0 && n_points == 0) return fail(ctx, DDDMR_ERR_BAD_ARG, "set_scan: empty scan with the stitcher on");
+  if (source >= 0) {
+    ctx->multi_source = true;
+    if (!ctx->src_cloud[source]) HIPCHK(ctx, hipMalloc(&ctx->src_cloud[source], (size_t)std::max<uint32_t>(ctx->cfg.max_points, 1) * sizeof(float4)));
+  }
   const int back = acquire_back(ctx);
   FeedParams fp;
   quat_to_rot(T_base_sensor, fp.Rbs);
@@ -715,14 +743,47 @@ int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_po
   fp.window = (float)perception_window_size;
   fp.height = (float)marking_height;
   uint32_t n_out = 0;
-  const int rc = perception_feed(ctx->feed, fp, xyz, stride_bytes, ctx->cloud_dev[back], ctx->copy_stream, &n_out);
+  float4* dst = source >= 0 ? ctx->src_cloud[source] : ctx->cloud_dev[back];
+  const int rc = perception_feed(*scratch, fp, xyz, stride_bytes, dst, ctx->copy_stream, &n_out);
   if (rc == -2) return fail(ctx, DDDMR_ERR_CAPACITY, "set_scan: the (stitched) scan exceeds max_points %u", ctx->cfg.max_points);
   if (rc != 0) return fail(ctx, DDDMR_ERR_HIP, "set_scan: perception feed failed (%d)", rc);
+  uint32_t n_all = n_out;
+  if (source >= 0) {
+    // the aggregate = every sensor's latest observation, in sensor order (aggregateObservations' loop over the plugins)
+    ctx->src_n[source] = n_out;
+    size_t total = 0;
+    for (int i = 0; i < dddmr_rollout_ctx::kMaxSources; ++i) total += ctx->src_n[i];
+    if (total > ctx->cfg.max_points) return fail(ctx, DDDMR_ERR_CAPACITY, "set_scan: the sensors' observations together (%zu points) exceed max_points %u", total, ctx->cfg.max_points);
+    size_t at = 0;
+    for (int i = 0; i < dddmr_rollout_ctx::kMaxSources; ++i) {
+      if (!ctx->src_n[i]) continue;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->cloud_dev[back] + at, ctx->src_cloud[i], (size_t)ctx->src_n[i] * sizeof(float4), hipMemcpyDeviceToDevice, ctx->copy_stream));
+      at += ctx->src_n[i];
+    }
+    n_all = (uint32_t)total;
+  }
   // the tick's stream waits on this event, so the feed kernels need not have retired yet
   HIPCHK(ctx, hipEventRecord(ctx->cloud_ready[back], ctx->copy_stream));
-  publish_cloud(ctx, back, n_out);
+  publish_cloud(ctx, back, n_all);
   if (n_out_points) *n_out_points = n_out;
+  if (n_aggregate) *n_aggregate = n_all;
   return DDDMR_OK;
+}
+
+int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_points,
+                           size_t stride_bytes, const double T_base_sensor[7],
+                           const double T_gbl_base[7], double perception_window_size,
+                           double marking_height, uint32_t* n_out_points) {
+  return set_scan_impl(ctx, -1, xyz, n_points, stride_bytes, T_base_sensor, T_gbl_base, perception_window_size, marking_height, n_out_points, nullptr);
+}
+
+int dddmr_rollout_set_scan_source(dddmr_rollout_ctx* ctx, int32_t source_id, const float* xyz, size_t n_points,
+                                  size_t stride_bytes, const double T_base_sensor[7], const double T_gbl_base[7],
+                                  double perception_window_size, double marking_height, uint32_t* n_source_points,
+                                  uint32_t* n_aggregate_points) {
+  if (source_id < 0) return ctx ? fail(ctx, DDDMR_ERR_BAD_ARG, "set_scan_source: source %d", source_id) : DDDMR_ERR_BAD_ARG;
+  return set_scan_impl(ctx, source_id, xyz, n_points, stride_bytes, T_base_sensor, T_gbl_base, perception_window_size, marking_height,
+                       n_source_points, n_aggregate_points);
 }
 
 int dddmr_rollout_set_stitcher(dddmr_rollout_ctx* ctx, int32_t stitcher_num) {
@@ -730,6 +791,21 @@ int dddmr_rollout_set_stitcher(dddmr_rollout_ctx* ctx, int32_t stitcher_num) {
   std::lock_guard<std::mutex> prod(ctx->producer_mu);
   ctx->feed.stitcher_num = stitcher_num;
   ctx->feed.stitched.clear();
+  return DDDMR_OK;
+}
+
+int dddmr_rollout_set_stitcher_source(dddmr_rollout_ctx* ctx, int32_t source_id, int32_t stitcher_num) {
+  if (!ctx || stitcher_num < 0 || source_id < 0 || source_id >= dddmr_rollout_ctx::kMaxSources) return DDDMR_ERR_BAD_ARG;
+  if (source_id == 0) return dddmr_rollout_set_stitcher(ctx, stitcher_num);
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::lock_guard<std::mutex> prod(ctx->producer_mu);
+  if (!ctx->src_feed[source_id]) {
+    auto* ps = new PerceptionScratch();
+    if (perception_alloc(*ps, ctx->cfg.max_points) != 0) { perception_free(*ps); delete ps; return fail(ctx, DDDMR_ERR_HIP, "set_stitcher: scratch of source %d", source_id); }
+    ctx->src_feed[source_id] = ps;
+  }
+  ctx->src_feed[source_id]->stitcher_num = stitcher_num;
+  ctx->src_feed[source_id]->stitched.clear();
   return DDDMR_OK;
 }
 
@@ -1194,6 +1270,28 @@ int tick_enqueue(dddmr_rollout_ctx* ctx, const char* theory_name, const dddmr_ti
   k.use_assign = (!ctx->no_assign && k.n_tiles > 1 && k.n_local <= kAssignMax && ctx->load_theory == theory_id &&
                   ctx->load_nlocal == k.n_local) ? 1 : 0;
   if (k.use_assign) k.n_tiles = (k.n_tiles + k.assign_groups - 1) / k.assign_groups * k.assign_groups;
+  k.nb_tiles = k.n_tiles;
+  k.r0 = 0;
+  // Several rounds of resident workgroups: full workgroups for the whole rounds, ONE last round of short workgroups
+  // for the rest (rollout_kernels.hip.h, tile_slot()); the lightest trajectories of the load-feedback deal land in it.
+  // Built, bit-identical, measured and left OFF (DDDMR_TAIL_ROUND=1): a k_score workgroup's life is mostly fixed cost
+  // (staging, ~13 barriers, scans), so 512 two-trajectory workgroups cost the C3 launch what its 171 full ones did:
+  // C3 tick 156.2 -> 159.1 us, C4 337.3 -> 330.3 us (profiles/r03_tail_round.txt).
+  if (!one_round && tile > 1 && ctx->tail_round && k.n_local <= kAssignMax) {
+    const int G = k.assign_groups;
+    const long slots = (long)ctx->n_cu * (thr == 512 ? 2 : 4);
+    const long whole = (long)k.n_local / (slots * tile);                         // rounds of full workgroups
+    const long rem = (long)k.n_local - whole * slots * tile;
+    const int t2 = (int)((rem + slots - 1) / slots);                             // trajectories of a short workgroup
+    if (whole >= 1 && rem > 0 && t2 < tile) {
+      const int nb = (int)((whole * slots + G - 1) / G * G), ns = (int)((slots + G - 1) / G * G);
+      if ((long)nb * tile + (long)ns * t2 >= k.n_local) {
+        k.nb_tiles = nb;
+        k.n_tiles = nb + ns;
+        k.r0 = tile - t2;
+      }
+    }
+  }
   ctx->load_theory = theory_id;
   ctx->load_nlocal = k.n_local;
   if (k.n_points > 0) {

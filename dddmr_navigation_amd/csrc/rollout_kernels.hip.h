@@ -47,6 +47,23 @@ namespace dddmr {
 // kScoreThreads): 512 lanes halve the collision walk of the heaviest tile and win when
 // the shard fits one round of resident workgroups (C2); 256 lanes keep more, smaller
 // workgroups in flight and win on big batches (C3, C4).
+// Hand-offs inside a launch (binning ticket -> cell scan; winner slots -> ticket -> slot reduction).  What crosses
+// workgroups is written ONLY by device-scope atomics or relaxed agent-scope atomic stores (global_store ... sc1: written
+// through past the XCD's L2) and read back by agent-scope atomic loads (sc1); the writer then waits for its own
+// operations (`s_waitcnt vmcnt(0)`, an asm statement with a memory clobber: the compiler moves nothing across it) before
+// one RELAXED device-scope add on the ticket.  In HSA memory-model terms this is a release on the ticket restricted to the
+// locations that matter.  Spelled as such (-DDDDMR_HANDOFF_ACQREL: __ATOMIC_ACQ_REL on the ticket) the compiler emits
+// `buffer_wbl2 sc1` + `buffer_inv sc1` around the atomic -- a write-back of the XCD's whole L2 per workgroup, measured at
+// +8.5 / +8.2 us per C2 / C3 tick on MI355X (profiles/r03_handoff.txt; the marking layer's last launch lost 120 us to the same
+// fence, profiles/r03_C5M_fused_kernel_stats.csv history in DESIGN.md).  The relaxed form is kept; the instruction
+// sequence it relies on (sc1 stores, s_waitcnt vmcnt(0), global_atomic_add ... sc1) is committed with the ROCm version it
+// was checked on in profiles/r03_handoff.txt and re-checked by tools/check_handoff_isa.py after any toolchain update.
+#ifdef DDDMR_HANDOFF_ACQREL
+#define DDDMR_HANDOFF_ORDER __ATOMIC_ACQ_REL
+#else
+#define DDDMR_HANDOFF_ORDER __ATOMIC_RELAXED
+#endif
+
 constexpr int kBinPer = 4;            // points per lane and pass of a binning workgroup
 constexpr int kRolloutMax = 128;      // trajectories per rollout workgroup (phase A: a lane each, C: two), at most
 constexpr int kBinThreads = 1024;     // k_bin_count workgroup (its last workgroup scans 4096 cells per step)
@@ -109,6 +126,8 @@ struct DevTick {
   int axes_inline;
   int use_assign;    // 1: tiles take their trajectories from assign[] (load feedback), 0: strided
   int n_tiles;       // k_score workgroups of this tick (a multiple of assign_groups)
+  int nb_tiles;      // the first nb_tiles workgroups take part in every round of the deal, the others only from round r0 on
+  int r0;            //   (nb_tiles = n_tiles, r0 = 0: every workgroup gets `tile` trajectories; see tile_slot())
   int assign_groups; // assignment workgroups
   int rows_cap;      // cell rows one cuboid AABB can span with this tick's cell size (<= kRows)
   int rt;            // trajectories per rollout workgroup
@@ -648,6 +667,19 @@ __device__ __forceinline__ void rollout_block(const DevTick& k, const int block,
 // to g (n_tiles is a multiple of the group count), so every group deals a
 // representative sample of the shard to its own tiles.  Whatever the loads hold
 // (first tick: zeros), the result is a permutation.
+// Slots of the deal.  Round r of the deal is nb_tiles slots wide while r < r0 and n_tiles wide from then on: workgroup b <
+// nb_tiles owns one slot of every round (up to `tile` trajectories), a workgroup beyond that only of the rounds r >= r0
+// (tile - r0 trajectories).  With DDDMR_TAIL_ROUND=1 a shard that needs several rounds of resident workgroups is laid out
+// so that the workgroups with all their trajectories fill whole rounds and ONE last round of short workgroups takes the
+// rest (measured: no gain, rollout_engine.hip; the default keeps nb_tiles = n_tiles, r0 = 0).  Slots are
+// numbered round by round, so slot s of round r belongs to workgroup s - base(r), and base(r) is a multiple of the
+// assignment groups: group g owns exactly the slots = g (mod groups), as before.
+__device__ __forceinline__ int tile_round_base(const DevTick& k, int r) {
+  return r < k.r0 ? r * k.nb_tiles : k.r0 * k.nb_tiles + (r - k.r0) * k.n_tiles;
+}
+__device__ __forceinline__ int tile_slot(const DevTick& k, int b, int j) {     // j-th slot of workgroup b
+  return tile_round_base(k, b < k.nb_tiles ? j : j + k.r0) + b;
+}
 constexpr int kAssignPer = 4;          // trajectories per lane of an assignment block (held in registers)
 template <int kThreads>
 __device__ __forceinline__ void assign_block(const DevTick& k, const int grp, const uint32_t* __restrict__ load,
@@ -658,8 +690,19 @@ __device__ __forceinline__ void assign_block(const DevTick& k, const int grp, co
   static_assert(kLoadClasses == kThreads, "one class per lane in the scan");
   const int tid = threadIdx.x;
   const int G = k.assign_groups;
-  const int n = k.n_local, n_tiles = k.n_tiles, tl = n_tiles / G;
+  const int n = k.n_local, tl = k.n_tiles / G, tlb = k.nb_tiles / G;     // slots of this group per late / early round
   const int ng = (n - grp + G - 1) / G;              // trajectories (and slots) of this group
+  // r-th slot of the group in deal order (its slots are the indices = grp (mod G), see tile_slot()): round, position
+  // in the round, and the snake: odd rounds run backwards while the round is complete
+  auto group_slot = [&](int r) {
+    const int early = k.r0 * tlb;
+    int start, width, round;
+    if (r < early) { round = r / tlb; start = round * tlb; width = tlb; }
+    else { round = k.r0 + (r - early) / tl; start = early + (round - k.r0) * tl; width = tl; }
+    const int pos = r - start;
+    const int bl = ((round & 1) && start + width <= ng) ? width - 1 - pos : pos;
+    return grp + G * (start + bl);
+  };
   DDDMR_RSTAMP(0);
   hist[tid] = 0;
   if (tid == 0) { mx_s = 1; mn_s = 0xFFFFFFFFu; }
@@ -679,16 +722,12 @@ __device__ __forceinline__ void assign_block(const DevTick& k, const int grp, co
   __syncthreads();
   if ((tid & 63) == 0) { atomicMax(&mx_s, mx); atomicMin(&mn_s, mn); }
   __syncthreads();
-  const int full_rounds = n / n_tiles;
   if (mx_s <= mn_s) {
     // all loads equal (e.g. no cloud): nothing to balance, deal in index order
 #pragma unroll
     for (int e = 0; e < kAssignPer; ++e) {
       const int m = tid + e * kThreads;
-      if (m < ng) {
-        const int round = m / tl, bl = m - round * tl;
-        assign[(size_t)round * n_tiles + grp + G * bl] = (uint32_t)(grp + G * m);
-      }
+      if (m < ng) assign[grp + G * m] = (uint32_t)(grp + G * m);
     }
     return;
   }
@@ -714,9 +753,7 @@ __device__ __forceinline__ void assign_block(const DevTick& k, const int grp, co
     if (m < ng) {
       const int c = kLoadClasses - 1 - min(kLoadClasses - 1, (int)((float)v[e] * scale));
       const int r = (int)atomicAdd(&hist[c], 1u);
-      const int round = r / tl, pos = r - round * tl;
-      const int bl = ((round & 1) && round < full_rounds) ? tl - 1 - pos : pos;
-      assign[(size_t)round * n_tiles + grp + G * bl] = (uint32_t)(grp + G * m);
+      assign[group_slot(r)] = (uint32_t)(grp + G * m);
     }
   }
   DDDMR_RSTAMP(3);
@@ -803,11 +840,11 @@ __global__ __launch_bounds__(kBinThreads, 8) void k_bin_count(DevTick k, const f
   // those are touched exclusively by device-scope atomics (returned => performed)
   // and read back with device-scope atomic loads, so no cache write-back /
   // invalidate is needed: every wave drains its atomics, barrier, one relaxed
-  // device-scope add per workgroup.
+  // device-scope add per workgroup.  (DDDMR_HANDOFF_ORDER: see the hand-off note above k_score.)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, DDDMR_HANDOFF_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     is_last = (t == (uint32_t)k.bin_blocks - 1) ? 1u : 0u;
     if (is_last) {
       *ticket = 0;            // next tick
@@ -1146,9 +1183,9 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
   // trajectories of those indices: neighbours in sample order head the same way and
   // would make whole tiles cheap (open space) or expensive (along a wall); striding
   // mixes them.
-  const int n_tiles = gridDim.x;
   const int tb = (int)blockIdx.x;
-  const int nt = (k.n_local - tb + n_tiles - 1) / n_tiles;   // <= tile
+  int nt = 0;                                                  // <= tile (see tile_slot())
+  for (int j = 0; j < tile; ++j) nt += ((tb < k.nb_tiles || j + k.r0 < tile) && tile_slot(k, tb, j) < k.n_local) ? 1 : 0;
 
   DDDMR_STAMP(0);
   // ---- stage the prune plan (float xyz, model_shared_data.h:83-91) ----
@@ -1156,7 +1193,7 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
 
   // ---- phase A: trajectory headers from k_rollout ----
   if (tid < nt) {
-    const int slot = tb + tid * n_tiles;
+    const int slot = tile_slot(k, tb, tid);
     const int li = k.use_assign ? (int)assign[slot] : slot;
     const TrajInfo ti = info[li];
     if (ti.over) atomicOr(overflow, 1u);
@@ -1849,7 +1886,7 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
     // stores drained, one relaxed device-scope ticket, and the wave that draws the last one reduces
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t t = 0;
-    if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1u, DDDMR_HANDOFF_ORDER, __HIP_MEMORY_SCOPE_AGENT);
     t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
     DDDMR_STAMP_RAW(15);
     if (t == gridDim.x - 1) {

@@ -124,6 +124,25 @@ class LocalPlanner:
                                                      C.byref(n_out)))
         return int(n_out.value)
 
+    def set_scan_source(self, source_id: int, scan_xyz: np.ndarray, T_base_sensor, T_gbl_base, perception_window_size: float,
+                        marking_height: float):
+        """One of several sensors (StackedPerception::aggregateObservations, stacked_perception.cpp:128-140): returns
+        (points of this sensor's observation, points of the aggregate = all sensors' latest observations in source order)."""
+        scan = np.ascontiguousarray(scan_xyz, dtype=np.float32)
+        if scan.ndim != 2 or (scan.shape[0] and scan.shape[1] < 3):
+            raise ValueError("scan must be [P, >=3] float32")
+        tbs = (C.c_double * 7)(*[float(v) for v in T_base_sensor])
+        tgb = (C.c_double * 7)(*[float(v) for v in T_gbl_base])
+        n_src, n_all = C.c_uint32(0), C.c_uint32(0)
+        stride = scan.strides[0] if scan.shape[0] else 12
+        self._check(self._lib.dddmr_rollout_set_scan_source(self._ctx, int(source_id), scan.ctypes.data_as(C.c_void_p), scan.shape[0],
+                                                            stride, tbs, tgb, perception_window_size, marking_height,
+                                                            C.byref(n_src), C.byref(n_all)))
+        return int(n_src.value), int(n_all.value)
+
+    def set_stitcher_source(self, source_id: int, stitcher_num: int):
+        self._check(self._lib.dddmr_rollout_set_stitcher_source(self._ctx, int(source_id), int(stitcher_num)))
+
     def set_stitcher(self, stitcher_num: int):
         """cbSensor's `stitcher_num` (multilayer_spinning_lidar.cpp:185-200): feed the last N raw scans together."""
         self._check(self._lib.dddmr_rollout_set_stitcher(self._ctx, int(stitcher_num)))

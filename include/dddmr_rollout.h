@@ -238,6 +238,22 @@ int dddmr_rollout_set_scan(dddmr_rollout_ctx* ctx, const float* xyz, size_t n_po
    max_points. */
 int dddmr_rollout_set_stitcher(dddmr_rollout_ctx* ctx, int32_t stitcher_num);
 
+/* Several sensors on one aggregate: StackedPerception::aggregateObservations
+   (dddmr_perception_3d/src/stacked_perception.cpp:128-140) concatenates every sensor plugin's
+   current observation, in plugin order.  source_id = the sensor's position in that order
+   (0 .. DDDMR_MAX_SOURCES - 1); each call runs that sensor's cbSensor on the device and the aggregate
+   becomes the concatenation, in source order, of every source's LATEST observation (a source that has
+   not reported yet contributes nothing).  *n_source_points / *n_aggregate_points (either may be NULL)
+   receive the two sizes.  The first call with a source id switches the context to this mode; plain
+   dddmr_rollout_set_scan then means source 0.  The observations together must fit max_points. */
+#define DDDMR_MAX_SOURCES 4
+int dddmr_rollout_set_scan_source(dddmr_rollout_ctx* ctx, int32_t source_id, const float* xyz,
+                                  size_t n_points, size_t stride_bytes, const double T_base_sensor[7],
+                                  const double T_gbl_base[7], double perception_window_size,
+                                  double marking_height, uint32_t* n_source_points,
+                                  uint32_t* n_aggregate_points);
+int dddmr_rollout_set_stitcher_source(dddmr_rollout_ctx* ctx, int32_t source_id, int32_t stitcher_num);
+
 /* Copy the current aggregate observation back (debug / parity of set_scan). */
 int dddmr_rollout_get_cloud(dddmr_rollout_ctx* ctx, float* xyzi_out, size_t capacity,
                             size_t* n_points);
@@ -428,7 +444,7 @@ int dddmr_rollout_marking_get_voxels(dddmr_rollout_ctx* ctx, int32_t* xyz_out, s
    lethal set (lethal_map_ keys) as one byte per ground node. */
 int dddmr_rollout_marking_get_dgraph(dddmr_rollout_ctx* ctx, double* values_out, size_t capacity);
 int dddmr_rollout_marking_get_lethal(dddmr_rollout_ctx* ctx, uint8_t* flags_out, size_t capacity);
-/* Which route the updates took (observations of up to 16384 points run fused: four launches, no
+/* Which route the updates took (observations of up to 16384 points run fused: six launches, no
    copies; larger ones take the general route with library sorts; DDDMR_MARKING_ROUTE=general|fused
    forces one) and how many kernels / memsets the last update launched.  Diagnostics, any pointer
    may be NULL. */

@@ -175,3 +175,59 @@ def test_random_stitched_scan_sequences(seed):
             if n:
                 d, idx = cKDTree(ref[:, :3]).query(got)
                 assert d.max() <= 1e-5 and len(np.unique(idx)) == len(ref)
+
+
+def _match(got_xyz, ref_xyz):
+    from scipy.spatial import cKDTree
+    assert len(got_xyz) == len(ref_xyz)
+    if len(ref_xyz) == 0:
+        return
+    d, idx = cKDTree(ref_xyz).query(got_xyz)
+    assert d.max() <= 1e-5 and len(np.unique(idx)) == len(ref_xyz)
+
+
+def test_two_sensors_concatenate_on_the_device_like_aggregate_observations():
+    """StackedPerception::aggregateObservations (stacked_perception.cpp:128-140) concatenates every sensor plugin's current
+    observation in plugin order: two lidars on different mounts feed the device through dddmr_rollout_set_scan_source; the
+    aggregate must be [sensor 0's latest | sensor 1's latest], each equal to the oracle's cbSensor of that scan, whichever
+    sensor reported last; a third report replaces only its own part; the stitcher state is per sensor."""
+    cloud = scenes.cloud_c2()
+    tgb = (1.0, -0.5, 0.0) + scenes.quat_from_rpy(0.0, 0.0, 0.3)
+    mounts = [(0.2, 0.0, 0.5) + scenes.quat_from_rpy(0.0, 0.02, 0.0), (-0.25, 0.1, 0.9) + scenes.quat_from_rpy(0.0, -0.03, 3.1)]
+    scans = [scenes.lidar_scan(cloud, sensor_xyz=(1.0, -0.5, 0.5), seed=21), scenes.lidar_scan(cloud, sensor_xyz=(0.8, -0.4, 0.9), seed=22),
+             scenes.lidar_scan(cloud, sensor_xyz=(1.0, -0.5, 0.5), seed=23)]
+    ref = [oracle.feed(scans[0], mounts[0], tgb, 8.0, 1.8), oracle.feed(scans[1], mounts[1], tgb, 8.0, 1.8), oracle.feed(scans[2], mounts[0], tgb, 8.0, 1.8)]
+    th = configs.bench_theory("C2")
+    with LocalPlanner([th], max_points=60_000) as lp:
+        n1, all1 = lp.set_scan_source(1, scans[1], mounts[1], tgb, 8.0, 1.8)        # sensor 1 reports first
+        assert (n1, all1) == (len(ref[1]), len(ref[1]))
+        _match(lp.get_cloud()[:, :3], ref[1])
+        n0, all0 = lp.set_scan_source(0, scans[0], mounts[0], tgb, 8.0, 1.8)
+        assert (n0, all0) == (len(ref[0]), len(ref[0]) + len(ref[1]))
+        got = lp.get_cloud()[:, :3]
+        _match(got[:n0], ref[0])                                                      # source order, not arrival order
+        _match(got[n0:], ref[1])
+        n0b, allb = lp.set_scan_source(0, scans[2], mounts[0], tgb, 8.0, 1.8)        # sensor 0 again: only its part changes
+        assert (n0b, allb) == (len(ref[2]), len(ref[2]) + len(ref[1]))
+        got = lp.get_cloud()[:, :3]
+        _match(got[:n0b], ref[2])
+        _match(got[n0b:], ref[1])
+        assert lp.set_scan(scans[0], mounts[0], tgb, 8.0, 1.8) == len(ref[0])        # plain set_scan now means sensor 0
+        assert len(lp.get_cloud()) == len(ref[0]) + len(ref[1])
+        # stitcher of sensor 1 only: its part becomes the feed of [previous raw scan | this raw scan]
+        lp.set_stitcher_source(1, 2)
+        lp.set_scan_source(1, scans[1], mounts[1], tgb, 8.0, 1.8)
+        n1s, _ = lp.set_scan_source(1, scans[2], mounts[1], tgb, 8.0, 1.8)
+        ref_st = oracle.feed(np.concatenate([scans[1], scans[2]]), mounts[1], tgb, 8.0, 1.8)
+        assert n1s == len(ref_st)
+        got = lp.get_cloud()[:, :3]
+        _match(got[:len(ref[0])], ref[0])
+        _match(got[len(ref[0]):], ref_st)
+        with pytest.raises(Exception):
+            lp.set_scan_source(9, scans[0], mounts[0], tgb, 8.0, 1.8)
+    cap = max(len(sc) for sc in scans) + 16                                           # every raw scan fits, the two observations do not
+    if len(ref[0]) + len(ref[1]) > cap:
+        with LocalPlanner([th], max_points=cap) as lp:
+            lp.set_scan_source(0, scans[0], mounts[0], tgb, 8.0, 1.8)
+            with pytest.raises(Exception):
+                lp.set_scan_source(1, scans[1], mounts[1], tgb, 8.0, 1.8)
