@@ -62,6 +62,8 @@ struct MarkingState {
   int route = -1;                          // DDDMR_MARKING_ROUTE: -1 by size, 0 general (rocPRIM), 1 fused only
   uint32_t updates_fused = 0, updates_general = 0, launches_last = 0;
   float last_clear_ms = 0.f, last_mark_ms = 0.f;
+  uint32_t unmark_parts = 8;               // DDDMR_MKF_UNPARTS (tuning)
+  uint32_t fuse_cells = kFuseMaxCells;     // DDDMR_MKF_CELLS: cells of the fused route's observation grid (tuning)
 };
 
 void free_grid(GridBuf& b) {
@@ -385,6 +387,8 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     HIPCHK(ctx, hipMemset(m->counters, 0, sizeof(MarkCounters)));
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->host_out), sizeof(MarkCounters), hipHostMallocMapped));
     HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&m->host_out_dev), m->host_out, 0));
+    if (const char* e = std::getenv("DDDMR_MKF_UNPARTS")) m->unmark_parts = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
+    if (const char* e = std::getenv("DDDMR_MKF_CELLS")) m->fuse_cells = std::min<uint32_t>(kFuseMaxCells, std::max(4096, std::atoi(e)));
     if (const char* e = std::getenv("DDDMR_MARKING_ROUTE")) m->route = std::strcmp(e, "general") == 0 ? 0 : (std::strcmp(e, "fused") == 0 ? 1 : -1);
     HIPCHK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_mkf_groups), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPartLdsBytes));
     HIPCHK(ctx, hipEventCreate(&m->e0));
@@ -611,10 +615,7 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   const PointGrid prev_grid = m->prev >= 0 ? m->obs[m->prev].g : empty_grid;
   if (mark) {
     float lo[3], hi[3];
-    uint32_t cap = std::min(gb.cap_cells, kFuseMaxCells);
-#ifdef DDDMR_PHASE_STAMPS
-    if (const char* e = std::getenv("DDDMR_MKF_CELLS")) cap = std::min<uint32_t>(cap, (uint32_t)std::atoi(e));
-#endif
+    const uint32_t cap = std::min(gb.cap_cells, m->fuse_cells);
     obs_grid_shape(m, f, cap, gb.g, lo, hi);
     gb.g.n = n_obs;
   }
@@ -656,13 +657,15 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   if (timed) HIPCHK(ctx, hipEventRecord(m->e1, st));
   // 4: seeds | removePCPtr of the cleared markings: ground node by ground node, point by point for the points that found no band
   {
-    uint32_t nb_roots = mark ? (n_obs + 255) / 256 : 0, nb_un = n_alive ? nb_band : 0u, nb_walk = n_alive ? 64u : 0u;
+    // (the removed markings of one update are a tenth of the new generator points: fewer, longer blocks per row)
+    const uint32_t n_part_un = m->unmark_parts;
+    uint32_t nb_roots = mark ? (n_obs + 255) / 256 : 0, nb_un = (n_alive && rg.bands) ? rg.rows * seg_groups * n_part_un : 0u, nb_walk = n_alive ? 64u : 0u;
 #ifdef DDDMR_PHASE_STAMPS
     if (const char* e = std::getenv("DDDMR_MKF_EXP")) { if (std::atoi(e) & 32) nb_un = 0; if (std::atoi(e) & 64) nb_walk = 0; }
 #endif
     if (nb_roots + nb_un + nb_walk)
       MK_LAUNCH(m, k_mkf_roots_unmark, dim3(nb_roots + nb_un + nb_walk), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters, nb_roots,
-                nb_un, seg_groups, n_part);
+                nb_un, seg_groups, n_part_un);
   }
   // 5: 64 partitions of the clusters
   if (mark)

@@ -18,21 +18,25 @@ gn = {32: "start", 33: "zero + count", 34: "scan", 35: "scatter"}
 with LocalPlanner([sc.theory], max_points=1 << 16) as lp:
     layer = marking.BenchMarking(lp, sc).layer if window == 10.0 else marking.MarkingLayer(
         lp, marking.shipped_config(perception_window_size=window), marking.ground_lattice(), np.zeros((0, 3), np.float32))
-    acc = np.zeros(64)
+    acc = np.zeros(64); last = None
     n = 0
     for i in range(30):
         lp.set_scan(scans[i % 10], t_bs, t_gb, window, 2.0)
         st = layer.update(t_bs, t_gb)
-        buf = np.zeros(64, dtype=np.uint64)
-        assert lib.dddmr_rollout_diag_mkstamps(buf.ctypes.data_as(C.c_void_p), 64) == 0
+        buf = np.zeros(192, dtype=np.uint64)
+        assert lib.dddmr_rollout_diag_mkstamps(buf.ctypes.data_as(C.c_void_p), 192) == 0
         if i >= 10:
-            acc += buf.astype(np.float64); n += 1
+            acc += buf[:64].astype(np.float64); n += 1; last = buf[64:].copy()
     acc /= n
     print("observation", st.n_observation, "clusters", st.n_clusters, "alive", st.n_alive, layer.route_counts())
     print("partition 0 (kilo-ticks of s_memtime):")
     for i in range(1, 10):
         print(f"  {names[i]:24s} {(acc[i] - acc[i-1]) / 1000.0:9.2f}")
     print(f"  total                    {(acc[9] - acc[0]) / 1000.0:9.2f}")
+    pm = (last >> np.uint64(40)).astype(np.int64); pt = (last & np.uint64((1 << 40) - 1)).astype(np.float64) / 1000.0
+    order = np.argsort(-pt)
+    print("partitions of the last update (points, kilo-ticks), slowest first:", [(int(pm[i]), round(float(pt[i]), 1)) for i in order[:12]],
+          "... median", (int(np.median(pm[pm > 0])), round(float(np.median(pt[pm > 0])), 1)))
     print("grid block:")
     for i in range(33, 36):
         print(f"  {gn[i]:24s} {(acc[i] - acc[i-1]) / 1000.0:9.2f}")
