@@ -551,15 +551,23 @@ def main():
         t_ms = float(np.mean(dev_ms)) if dev_ms else float("nan")
         achieved = compulsory / (k_ms * 1e-3) / 1e9
         prof = {}
-        for fn in ("traffic.json", "r02_pmc.json", "r02_kernel_avg.json"):
-            pth = os.path.join(ROOT, "profiles", fn)
-            if os.path.exists(pth):
+        prof_src = {}
+        for fn, cands in (("traffic.json", ("traffic.json",)), ("pmc.json", ("r03_pmc.json", "r02_pmc.json")),
+                          ("kernel_avg.json", ("r03_kernel_avg.json", "r02_kernel_avg.json"))):
+            prof[fn] = {}
+            for cand in cands:                                # the newest round's table that has this workload
+                pth = os.path.join(ROOT, "profiles", cand)
+                if not os.path.exists(pth):
+                    continue
                 try:
-                    prof[fn] = json.load(open(pth)).get(f"{workload}" if layout == scenes.DEFAULT_LAYOUT else f"{workload}_{layout}", {})
+                    got = json.load(open(pth)).get(f"{workload}" if layout == scenes.DEFAULT_LAYOUT else f"{workload}_{layout}", {})
                 except Exception:
-                    prof[fn] = {}
+                    got = {}
+                if got:
+                    prof[fn], prof_src[fn] = got, "profiles/" + cand
+                    break
         traffic = prof.get("traffic.json", {}).get("k_score_hbm_bytes_per_launch") if world == 1 else None
-        pmc = prof.get("r02_pmc.json", {})
+        pmc = prof.get("pmc.json", {})
         roofline = {
             "bound": "hbm", "kernel": "k_score",
             "achieved": round(achieved, 2), "peak": 8000.0, "unit": "GB/s", "frac": round(achieved / 8000.0, 4),
@@ -573,14 +581,14 @@ def main():
             "b_alg_bytes": ref_bytes,
             "bytes_per_launch": compulsory, "units_per_launch": units,
             "bytes_per_unit": round(compulsory / max(units, 1), 2),
-            "kernel_ms": round(k_ms, 5), "kernel_ms_rocprofv3": prof.get("r02_kernel_avg.json", {}).get("k_score_ms"),
-            "kernel_ms_rocprofv3_static": True,
+            "kernel_ms": round(k_ms, 5), "kernel_ms_rocprofv3": prof.get("kernel_avg.json", {}).get("k_score_ms"),
+            "kernel_ms_rocprofv3_static": True, "kernel_ms_rocprofv3_source": prof_src.get("kernel_avg.json"),
             "tick_device_ms": round(t_ms, 5),
             "what_binds_it": {
                 "name": "VALU issue + memory/LDS latency (not HBM: the working set is L2/MALL resident)",
                 "valu_busy_frac_of_issue_cycles": pmc.get("valu_busy_frac"),
                 "waves_waiting_frac": pmc.get("waves_waiting_frac"),
-                "static": True, "source": "profiles/r02_pmc.json (an earlier run, not this one)" if pmc else None},
+                "static": True, "source": (prof_src.get("pmc.json", "") + " (an earlier run, not this one)") if pmc else None},
             "stream_ceiling": ceiling,
             "frac_of_copy_ceiling": round(achieved / ceiling["copy_GBps"], 4) if ceiling else None,
             "reference_equivalent_gather": {

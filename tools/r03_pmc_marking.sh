@@ -6,7 +6,7 @@ ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_$TAG; mkdir -p $OUT
 export PYTHONPATH=$ROOT TMPDIR=/tmp DDDMR_MARKING_ROUTE=$ROUTE; cd /tmp
 P1="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_ANY"
 P2="SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_INSTS_LDS SQ_WAIT_INST_LDS"
-P3="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_ATOMIC_sum TCC_WRITE_sum TCC_READ_sum"
+P3="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum"   # (TCC_ATOMIC / WRITE / READ_sum abort rocprofv3 on this image)
 i=1
 for P in "$P1" "$P2" "$P3"; do
   timeout -k 5 240 rocprofv3 --pmc $P --output-format csv -d $OUT/pmc$i -o pmc -- python3 $ROOT/bench.py --workload C5M --steps 40 --warmup 10 --no-cpu-baseline --no-ceiling > $OUT/pmc$i.log 2>&1 || { echo pmc$i failed; tail -3 $OUT/pmc$i.log; }
