@@ -199,6 +199,7 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_comm_init",
     "dddmr_rollout_comm_destroy",
     "dddmr_rollout_comm_ranks",
+    "dddmr_rollout_device_count",
     "dddmr_rollout_comm_loopback",
     "dddmr_rollout_comm_loopback_set_peer",
     "dddmr_rollout_marking_create",
@@ -290,6 +291,8 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_comm_init.restype = C.c_int
     lib.dddmr_rollout_comm_destroy.argtypes = [ctx_p]
     lib.dddmr_rollout_comm_destroy.restype = C.c_int
+    lib.dddmr_rollout_device_count.argtypes = [C.POINTER(C.c_int32)]
+    lib.dddmr_rollout_device_count.restype = C.c_int
     lib.dddmr_rollout_comm_ranks.argtypes = [ctx_p, C.POINTER(C.c_int32)]
     lib.dddmr_rollout_comm_ranks.restype = C.c_int
     lib.dddmr_rollout_comm_loopback.argtypes = [ctx_p]

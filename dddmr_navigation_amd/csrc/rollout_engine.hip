@@ -1601,6 +1601,15 @@ int dddmr_rollout_comm_destroy(dddmr_rollout_ctx* ctx) {
   return DDDMR_OK;
 }
 
+int dddmr_rollout_device_count(int32_t* n_out) {
+  if (!n_out) return DDDMR_ERR_BAD_ARG;
+  int n = 0;
+  *n_out = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return DDDMR_ERR_NO_DEVICE; }
+  *n_out = n;
+  return DDDMR_OK;
+}
+
 int dddmr_rollout_comm_ranks(dddmr_rollout_ctx* ctx, int32_t* n_ranks_out) {
   if (!ctx || !n_ranks_out) return DDDMR_ERR_BAD_ARG;
   std::lock_guard<std::mutex> tk(ctx->tick_mu);

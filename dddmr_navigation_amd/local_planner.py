@@ -48,6 +48,13 @@ class RolloutError(RuntimeError):
         self.code = code
 
 
+def device_count() -> int:
+    """HIP devices this process sees (0 without a GPU); through the library, so no torch import is needed."""
+    n = C.c_int32(0)
+    rc = K.load_library().dddmr_rollout_device_count(C.byref(n))
+    return int(n.value) if rc == K.OK else 0
+
+
 class LocalPlanner:
     """One rollout context = the trajectory generators + critics of one robot."""
 

@@ -342,6 +342,9 @@ int dddmr_rollout_comm_unique_id(uint8_t id_out[DDDMR_COMM_ID_BYTES]);
 int dddmr_rollout_comm_init(dddmr_rollout_ctx* ctx, const uint8_t id[DDDMR_COMM_ID_BYTES],
                             int32_t rank, int32_t n_ranks);
 int dddmr_rollout_comm_destroy(dddmr_rollout_ctx* ctx);
+/* HIP devices this process sees (hipGetDeviceCount): what a multi-GPU host places its contexts by
+   (`cfg.device`); the reference has no counterpart (one CPU process per robot). */
+int dddmr_rollout_device_count(int32_t* n_out);
 /* Ranks of the context's exchange as the communicator itself reports them (ncclCommCount), 0 without
    one: what a multi-GPU run prints next to its numbers. */
 int dddmr_rollout_comm_ranks(dddmr_rollout_ctx* ctx, int32_t* n_ranks_out);
