@@ -43,6 +43,9 @@ def parse():
                          "advances along the prune plan every tick and the cloud is replaced every --replace-every ticks "
                          "(always measured as config.moving_value on one GPU; --inputs moving makes it the headline value)")
     ap.add_argument("--replace-every", type=int, default=10)
+    ap.add_argument("--marking-schedule", choices=["overlapped", "serial"], default="overlapped",
+                    help="C5M: tick_begin -> marking update -> tick_end (the update on its own stream next to the tick's kernels, "
+                         "as the reference's perception and planner threads run side by side) or feed -> update -> tick one after the other")
     ap.add_argument("--no-extras", action="store_true", help="skip end_to_end / moving / shipped-latency measurements")
     ap.add_argument("--scene-layout", default=None, choices=["r02", "r01"],
                     help="r02 (default): ~25 %% colliding trajectories as SURVEY 8d specifies; r01: the round-1 scenes (69-86 %%)")
@@ -349,6 +352,7 @@ def main():
             lps.append(extra)
             inflight.append(False)
     last_res = [None]
+    overlap_marking = [marking is not None and args.marking_schedule == "overlapped"]
 
     def step():
         if len(lps) > 1:
@@ -363,6 +367,12 @@ def main():
             scan = scans[step_no[0] % len(scans)]
             lp.set_scan(scan, t_bs, t_gb, 10.0, 2.0)
             if marking is not None:
+                if overlap_marking[0]:
+                    lp.tick_begin(name, sc.tick)
+                    marking.update(scan, t_bs, t_gb)
+                    res = lp.tick_end()
+                    step_no[0] += 1
+                    return res
                 marking.update(scan, t_bs, t_gb)
         if reduce_mode == "inlib":
             res = lp.tick(name, sc.tick)                     # k_score -> ncclAllReduce -> resolve kernel, one stream
@@ -404,6 +414,22 @@ def main():
             dev_ms.append(lr.device_ms)               # ... and of the whole tick's kernels
     fence()
     elapsed = time.perf_counter() - t0
+    serial_ms, marking_summary = None, None
+    if marking is not None:
+        # the other schedule, and the update's HIP-event times with nothing else on the GPU (right away: the GPU is warm)
+        was = overlap_marking[0]
+        overlap_marking[0] = False
+        for _ in range(10):
+            step()
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(100):
+            res = step()
+        fence()
+        serial_ms = (time.perf_counter() - t1) / 100 * 1e3
+        overlap_marking[0] = was
+        marking_summary = marking.summary()
+        # (the parity check below looks at the cloud and the result of the LAST step, whichever schedule ran it)
     if reduce_mode == "torch":
         res = resolved[0]
     if len(lps) > 1:
@@ -682,7 +708,11 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if marking is not None:
-            ms = marking.summary()
+            ms = marking_summary
+            ms["schedule"] = args.marking_schedule
+            ms["serial_schedule_ms_per_step"] = round(serial_ms, 5)
+            ms["note"] = ("clear_ms / mark_ms: HIP events of an update running alone (serial schedule); `value` is measured on the "
+                          "schedule named here")
             out["config"]["marking"] = ms
             # the marking / clearing update against the HBM roofline: bytes it must move once (observation read by the grid
             # count, the scatter, the union-find and the partitions, 16 B each; grid cells; the store's slots; generator

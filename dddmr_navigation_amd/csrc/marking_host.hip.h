@@ -62,6 +62,9 @@ struct MarkingState {
   int route = -1;                          // DDDMR_MARKING_ROUTE: -1 by size, 0 general (rocPRIM), 1 fused only
   uint32_t updates_fused = 0, updates_general = 0, launches_last = 0;
   float last_clear_ms = 0.f, last_mark_ms = 0.f;
+  hipStream_t own_stream = nullptr;        // the update's stream while a tick_begin is pending (else the context's)
+  hipStream_t cur = nullptr;               // stream of the update in progress
+  uint32_t updates_overlapped = 0;
   uint32_t unmark_parts = 8;               // DDDMR_MKF_UNPARTS (tuning)
   uint32_t fuse_cells = kFuseMaxCells;     // DDDMR_MKF_CELLS: cells of the fused route's observation grid (tuning)
 };
@@ -96,6 +99,7 @@ void marking_free(MarkingState* m) {
     if (q) (void)hipFree(q);
   if (m->host_out) (void)hipHostFree(m->host_out);
   free_grid(m->ground); free_grid(m->map); free_grid(m->obs[0]); free_grid(m->obs[1]);
+  if (m->own_stream) (void)hipStreamDestroy(m->own_stream);
   if (m->e0) (void)hipEventDestroy(m->e0);
   if (m->e1) (void)hipEventDestroy(m->e1);
   if (m->e2) (void)hipEventDestroy(m->e2);
@@ -225,7 +229,7 @@ int upload_static(dddmr_rollout_ctx* ctx, MarkingState* m, GridBuf& b, float4** 
 int marking_fix_ties(dddmr_rollout_ctx* ctx, MarkingState* m, const MarkParams& k, const MarkStore& s, MarkCounters& out) {
   const uint32_t nc = out.n_clusters;
   if (nc == 0) return DDDMR_OK;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = m->cur;
   std::vector<uint32_t> size(nc), state(nc), slot(nc);
   HIPCHK(ctx, hipMemcpyAsync(size.data(), m->cl.size, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   HIPCHK(ctx, hipMemcpyAsync(state.data(), m->cl.state, nc * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -555,7 +559,7 @@ int mark_general(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
 // one update on the general route (~55 launches for a 6 k-point observation)
 int update_general(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, const float4* obs, uint32_t n_obs, bool timed,
                    MarkCounters& out) {
-  hipStream_t st = ctx->stream;
+  hipStream_t st = m->cur;
   const MarkParams& k = f.k;
   MarkStore& s = m->store;
   MarkCounters zero{};
@@ -595,7 +599,7 @@ int update_general(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f
 // one update on the fused route: six launches, no copies (marking_fused.hip.h)
 int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, const float4* obs, uint32_t n_obs, bool timed,
                  MarkCounters& out) {
-  hipStream_t st = ctx->stream;
+  hipStream_t st = m->cur;
   const MarkParams& k = f.k;
   MarkStore& s = m->store;
   if (!m->counters_clean) {
@@ -730,17 +734,36 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
   std::lock_guard<std::mutex> tk(ctx->tick_mu);
   MarkingState* m = ctx->marking;
   if (!m) return fail(ctx, DDDMR_ERR_STATE, "marking_update before marking_create");
-  if (ctx->pend.active) return fail(ctx, DDDMR_ERR_STATE, "marking_update while a tick_begin is pending");
   HIPCHK(ctx, hipSetDevice(ctx->device));
-  hipStream_t st = ctx->stream;
   const dddmr_marking_config& c = m->cfg;
-  // the observation = the context's published aggregate cloud (global frame), pinned like a tick pins it
-  bool pending;
-  const int cidx = pin_front(ctx, &pending);
-  struct Release { dddmr_rollout_ctx* c; ~Release() { release_cloud(c); } } release{ctx};
-  if (pending) {
-    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->cloud_ready[cidx], 0));
-    cloud_wait_done(ctx, cidx);
+  // The observation = the context's published aggregate cloud (global frame), pinned like a tick pins it.
+  // While a tick_begin is pending -- the reference runs the perception thread's doClear_then_Mark and the planner's
+  // tick side by side -- the update runs on a stream of its own, next to the tick's kernels (the two touch disjoint
+  // state), provided it reads the SAME observation the pending tick has pinned: a third pinned buffer would leave a
+  // producer none to write into.
+  const bool overlapped = ctx->pend.active;
+  int cidx;
+  struct Release { dddmr_rollout_ctx* c; ~Release() { if (c) release_cloud(c); } } release{nullptr};
+  if (overlapped) {
+    {
+      std::lock_guard<std::mutex> lk(ctx->cloud_mu);
+      if (ctx->busy < 0 || ctx->busy != ctx->front)
+        return fail(ctx, DDDMR_ERR_STATE, "marking_update while a tick_begin is pending: a newer observation was published after tick_begin");
+      cidx = ctx->busy;
+    }
+    if (!m->own_stream) HIPCHK(ctx, hipStreamCreateWithFlags(&m->own_stream, hipStreamNonBlocking));
+    m->cur = m->own_stream;
+    HIPCHK(ctx, hipStreamWaitEvent(m->cur, ctx->cloud_ready[cidx], 0));      // (the tick's stream has its own wait enqueued)
+    ++m->updates_overlapped;
+  } else {
+    bool pending;
+    cidx = pin_front(ctx, &pending);
+    release.c = ctx;
+    m->cur = ctx->stream;
+    if (pending) {
+      HIPCHK(ctx, hipStreamWaitEvent(m->cur, ctx->cloud_ready[cidx], 0));
+      cloud_wait_done(ctx, cidx);
+    }
   }
   const uint32_t n_obs = ctx->cloud_n[cidx];
   const float4* obs = ctx->cloud_dev[cidx];

@@ -352,3 +352,47 @@ def test_observation_larger_than_the_fused_route_takes_the_general_one(monkeypat
             np.testing.assert_array_equal(layer.dgraph(), mo.dgraph())
         rc = layer.route_counts()
         assert rc["fused"] == 1 and rc["general"] == 2, rc
+
+
+def test_update_next_to_a_pending_tick_gives_the_serial_results():
+    """tick_begin -> marking_update -> tick_end (the update on a stream of its own next to the tick's kernels: the
+    reference runs the perception thread's doClear_then_Mark and the planner's tick side by side) must leave the store,
+    the dGraph, the lethal set and every tick result exactly as set_scan -> marking_update -> tick does; and the update
+    is refused when a newer observation was published after tick_begin (it would need a third pinned cloud buffer)."""
+    sc, cloud, _, _ = _scene()
+    cfg = marking.shipped_config(perception_window_size=10.0)
+    ground = marking.ground_lattice()
+    name = sc.theory.name.decode()
+
+    def fields(r):
+        return (r.planner_state, r.best_index, r.best_cost, r.vx, r.vy, r.wz, r.n_points_binned)
+    with LocalPlanner([sc.theory], max_points=1 << 16) as a, LocalPlanner([sc.theory], max_points=1 << 16) as b:
+        la = marking.MarkingLayer(a, cfg, ground, np.zeros((0, 3), np.float32))
+        lb = marking.MarkingLayer(b, cfg, ground, np.zeros((0, 3), np.float32))
+        a.setPlan(sc.plan); b.setPlan(sc.plan)
+        for k in range(8):
+            t_gb = (0.3 * k, 0.05 * k, 0.0, 0, 0, math.sin(0.02 * k), math.cos(0.02 * k))
+            scene_k = cloud if k % 3 else cloud[: len(cloud) // 2]
+            scan = scenes.lidar_scan(scene_k, sensor_xyz=(t_gb[0], t_gb[1], 0.5), seed=300 + k)
+            a.set_scan(scan, T_BS, t_gb, 10.0, 2.0)
+            sa = la.update(T_BS, t_gb)
+            ra = a.tick(name, sc.tick)
+            b.set_cloud(a.get_cloud())                        # (the feed's centroids come from atomic sums: the same floats for both)
+            b.tick_begin(name, sc.tick)
+            sb = lb.update(T_BS, t_gb)
+            rb = b.tick_end()
+            assert fields(ra) == fields(rb)
+            assert (sa.n_observation, sa.n_clusters, sa.n_marked, sa.n_in_window, sa.n_cleared, sa.n_alive) == \
+                   (sb.n_observation, sb.n_clusters, sb.n_marked, sb.n_in_window, sb.n_cleared, sb.n_alive)
+            assert _vset(la.voxels()) == _vset(lb.voxels())
+            np.testing.assert_array_equal(la.dgraph(), lb.dgraph())
+            np.testing.assert_array_equal(la.lethal(), lb.lethal())
+        assert sa.n_alive > 100
+        # a newer observation after tick_begin: refused, nothing changes, the tick still ends
+        b.tick_begin(name, sc.tick)
+        b.set_scan(scenes.lidar_scan(cloud, sensor_xyz=(2.4, 0.4, 0.5), seed=999), T_BS, t_gb, 10.0, 2.0)
+        with pytest.raises(RolloutError) as e:
+            lb.update(T_BS, t_gb)
+        assert e.value.code == K.ERR_STATE
+        assert fields(b.tick_end())[:2] == fields(rb)[:2]
+        np.testing.assert_array_equal(la.dgraph(), lb.dgraph())
