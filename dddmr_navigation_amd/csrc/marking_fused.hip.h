@@ -90,6 +90,7 @@ struct FuseBufs {
   uint32_t* cell_count;    // [kFuseMaxCells] all zero between updates
   unsigned long long* slot;  // [n] (rank << 32) | cell of a point in the observation grid
   MarkCounters* host_out;  // host-mapped copy of the update's counters
+  uint32_t grid_in_lds;    // the observation grid is built by launch 2's first workgroups alone (no launch 1)
 };
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
@@ -217,6 +218,92 @@ __device__ __forceinline__ void fuse_grid_scan_scatter(const PointGrid& g, const
   MKF_STAMP(35);
 }
 
+// The same grid built from the points alone by `ng` workgroups (1, 2, 4 or 8), workgroup q owning the cells
+// [q, q + 1) * 65536 / ng: every workgroup reads ALL points, ranks the ones of its cells by LDS atomics on the packed 16-bit
+// counters (the returned old value is the rank) and counts the points of lower cells -- its base, so no workgroup waits for
+// another -- then scans, copies out and scatters its own share.  (cell, rank) of a lane's <= 16 points stay in registers
+// between the count and the scatter.  No launch 1, no 256 KB of global counters to read back and re-zero; the single
+// workgroup's 20 us (the launch's critical path: the slot blocks next to it take 9) divide by ng up to the count pass.
+__device__ __forceinline__ void fuse_grid_build_lds(const PointGrid& g, const float4* __restrict__ pts, uint32_t* __restrict__ parent,
+                                                    uint32_t* cnt2 /* [33 * 1024] */, uint32_t* wsum, const uint32_t part, const uint32_t ng) {
+  const int tid = threadIdx.x;
+  const uint32_t n = g.n, cells = (uint32_t)(g.nx * g.ny * g.nz);
+  const uint32_t wpt = 32u / ng;                               // counter words (two cells each) per lane
+  const uint32_t lw = 31u - (uint32_t)__clz((int)wpt);         // log2(wpt): word w lives at w + (w >> lw)
+  const uint32_t c_lo = part * (65536u / ng), c_hi = c_lo + 65536u / ng;
+  MKF_STAMP(32);
+  for (uint32_t j = 0; j <= wpt; ++j) cnt2[j * 1024u + tid] = 0u;
+  __syncthreads();
+  // all loads first, then all atomics, then the ranks: one latency each instead of sixteen in a row
+  float4 pt[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const uint32_t i = (uint32_t)s * 1024u + tid;
+    pt[s] = i < n ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  uint32_t pack[16];                                           // (cell - c_lo) | rank << 16; ~0: not mine
+  uint32_t lower = 0;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const uint32_t i = (uint32_t)s * 1024u + tid;
+    pack[s] = ~0u;
+    if (i < n) {
+      const uint32_t cell = (uint32_t)((grid_cz(g, pt[s].z) * g.ny + grid_cy(g, pt[s].y)) * g.nx + grid_cx(g, pt[s].x));
+      lower += cell < c_lo ? 1u : 0u;
+      if (cell >= c_lo && cell < c_hi) {
+        const uint32_t lc = cell - c_lo, wi = lc >> 1, sh = (lc & 1u) * 16u;
+        pack[s] = atomicAdd(&cnt2[wi + (wi >> lw)], 1u << sh);   // (the old word, for now)
+        pt[s].w = __uint_as_float(lc);
+      } else {
+        pt[s].w = __uint_as_float(~0u);
+      }
+      if (part == 0) parent[i] = i;
+    } else {
+      pt[s].w = __uint_as_float(~0u);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const uint32_t lc = __float_as_uint(pt[s].w);
+    pack[s] = lc == ~0u ? ~0u : (lc | (((pack[s] >> ((lc & 1u) * 16u)) & 0xFFFFu) << 16));
+  }
+  uint32_t base;
+  (void)block_excl_scan<16>(lower, wsum, &base);               // (ends with a barrier: the counts are complete too)
+  MKF_STAMP(33);
+  uint32_t sum = 0;
+  for (uint32_t j = 0; j < wpt; ++j) {
+    const uint32_t v = cnt2[tid * (wpt + 1u) + j];
+    sum += (v & 0xFFFFu) + (v >> 16);
+  }
+  uint32_t tot;
+  uint32_t run = base + block_excl_scan<16>(sum, wsum, &tot);
+  for (uint32_t j = 0; j < wpt; ++j) {
+    const uint32_t v = cnt2[tid * (wpt + 1u) + j];
+    const uint32_t a = v & 0xFFFFu, b = v >> 16;
+    cnt2[tid * (wpt + 1u) + j] = run | ((run + a) << 16);      // (starts <= 16384 fit 16 bits)
+    run += a + b;
+  }
+  __syncthreads();
+  uint4* cs4 = reinterpret_cast<uint4*>(g.cell_start + c_lo);
+  for (uint32_t j = 0; j < wpt / 2u; ++j) {                    // coalesced copy-out of the starts
+    const uint32_t q = j * 1024u + tid, c0 = c_lo + 4u * q, w = 2u * q;
+    const uint32_t v0 = cnt2[w + (w >> lw)], v1 = cnt2[w + 1u + ((w + 1u) >> lw)];
+    if (c0 < cells) cs4[q] = make_uint4(v0 & 0xFFFFu, v0 >> 16, v1 & 0xFFFFu, v1 >> 16);   // (entries past `cells` hold n: the scan ran on)
+  }
+  if (tid == 0 && part == 0) g.cell_start[cells] = n;
+  MKF_STAMP(34);
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const uint32_t i = (uint32_t)s * 1024u + tid;
+    if (pack[s] != ~0u) {
+      const uint32_t lc = pack[s] & 0xFFFFu, wi = lc >> 1;
+      const uint32_t st = (cnt2[wi + (wi >> lw)] >> ((lc & 1u) * 16u)) & 0xFFFFu;
+      g.sorted[st + (pack[s] >> 16)] = make_float4(pt[s].x, pt[s].y, pt[s].z, __int_as_float((int)i));
+    }
+  }
+  MKF_STAMP(35);
+}
+
 // launch 1: cell counts
 __global__ __launch_bounds__(256) void k_mkf_count(PointGrid obs, FuseBufs fb) { fuse_grid_count(obs, fb.pts, fb.parent, fb.cell_count, fb.slot); }
 
@@ -226,7 +313,8 @@ __global__ __launch_bounds__(1024) void k_mkf_grid_fov(MarkParams k, MarkStore s
   __shared__ uint32_t cnt2[33 * 1024];
   __shared__ uint32_t wsum[16];
   if (blockIdx.x < nb_grid) {
-    fuse_grid_scan_scatter(obs, fb.pts, fb.cell_count, fb.slot, cnt2, wsum);
+    if (fb.grid_in_lds) fuse_grid_build_lds(obs, fb.pts, fb.parent, cnt2, wsum, blockIdx.x, nb_grid);
+    else fuse_grid_scan_scatter(obs, fb.pts, fb.cell_count, fb.slot, cnt2, wsum);
     return;
   }
   // every slot of the store: no owner yet in this update; alive markings inside the window (integer test, one lane per

@@ -65,6 +65,8 @@ struct MarkingState {
   hipStream_t own_stream = nullptr;        // the update's stream while a tick_begin is pending (else the context's)
   hipStream_t cur = nullptr;               // stream of the update in progress
   uint32_t updates_overlapped = 0;
+  uint32_t grid_parts = 4;                 // DDDMR_MKF_GRIDPARTS: workgroups that build the observation grid (1, 2, 4, 8)
+  bool grid_in_lds = true;                 // DDDMR_MKF_GRID=global: counts by launch 1's global atomics instead
   uint32_t unmark_parts = 8;               // DDDMR_MKF_UNPARTS (tuning)
   uint32_t fuse_cells = kFuseMaxCells;     // DDDMR_MKF_CELLS: cells of the fused route's observation grid (tuning)
 };
@@ -391,6 +393,8 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     HIPCHK(ctx, hipMemset(m->counters, 0, sizeof(MarkCounters)));
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->host_out), sizeof(MarkCounters), hipHostMallocMapped));
     HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&m->host_out_dev), m->host_out, 0));
+    if (const char* e = std::getenv("DDDMR_MKF_GRIDPARTS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) m->grid_parts = (uint32_t)v; }
+    if (const char* e = std::getenv("DDDMR_MKF_GRID")) m->grid_in_lds = std::strcmp(e, "global") != 0;
     if (const char* e = std::getenv("DDDMR_MKF_UNPARTS")) m->unmark_parts = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("DDDMR_MKF_CELLS")) m->fuse_cells = std::min<uint32_t>(kFuseMaxCells, std::max(4096, std::atoi(e)));
     if (const char* e = std::getenv("DDDMR_MARKING_ROUTE")) m->route = std::strcmp(e, "general") == 0 ? 0 : (std::strcmp(e, "fused") == 0 ? 1 : -1);
@@ -640,14 +644,14 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   }
   FuseBufs fb{obs, m->parent, m->ds, m->gen, m->clear_list, m->unmark_pts,
               BandList{m->band_pts, m->band_cnt}, BandList{m->band_pts + (size_t)kBandMax * kBandCap, m->band_cnt + kBandMax}, rg,
-              m->ticket, m->cell_count, m->keys_a, m->host_out_dev};
+              m->ticket, m->cell_count, m->keys_a, m->host_out_dev, m->grid_in_lds ? 1u : 0u};
   const uint32_t seg_groups = (rg.segs + 3u) / 4u, n_part = 48u;
   const uint32_t nb_band = rg.bands ? rg.rows * seg_groups * n_part : 0u;
   // 1: cell counts of the observation grid
-  if (mark) MK_LAUNCH(m, k_mkf_count, dim3((n_obs + 255) / 256), dim3(256), 0, st, gb.g, fb);
+  if (mark && !m->grid_in_lds) MK_LAUNCH(m, k_mkf_count, dim3((n_obs + 255) / 256), dim3(256), 0, st, gb.g, fb);
   // 2: scan + scatter of the observation grid (one workgroup) | every store slot: window + FOV test -> ray-test list
   {
-    const uint32_t nb_grid = mark ? 1u : 0u;
+    const uint32_t nb_grid = mark ? (m->grid_in_lds ? m->grid_parts : 1u) : 0u;
     MK_LAUNCH(m, k_mkf_grid_fov, dim3(nb_grid + (m->table + 1023) / 1024), dim3(1024), 0, st, k, s, gb.g, fb, m->counters, nb_grid);
   }
   // 3: ray tests | union-find

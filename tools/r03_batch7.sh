@@ -1,0 +1,12 @@
+#!/bin/bash
+mkdir -p gpurun_out/r03
+export PYTHONPATH=$PWD
+for g in 1 4 8; do
+  echo "== grid parts $g"
+  DDDMR_MKF_GRIDPARTS=$g DDDMR_LIB_NAME=libdddmr_rollout_diag.so timeout -k 10 200 python tools/marking_stamps.py 2>&1 | grep -A4 "grid block"
+done
+for g in 4 8; do
+  DDDMR_MKF_GRIDPARTS=$g python bench.py --workload C5M --steps 300 --warmup 50 --no-ceiling --no-cpu-baseline > gpurun_out/r03/c5m_gp_$g.json 2> gpurun_out/r03/c5m_gp_$g.err
+  python -c "import json; d=json.load(open('gpurun_out/r03/c5m_gp_$g.json')); m=d['config']['marking']; print('grid parts $g', d['ms_per_step'], m['serial_schedule_ms_per_step'], m['clear_ms'], m['mark_ms'], d['config']['cmd_vel_matches_oracle'])" || tail -5 gpurun_out/r03/c5m_gp_$g.err
+done
+bash tools/r03_profile_marking.sh fused r03_C5M_fused > gpurun_out/r03/prof6.log 2>&1; head -8 gpurun_out/r03/prof6.log
