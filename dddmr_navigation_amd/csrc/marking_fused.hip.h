@@ -578,6 +578,22 @@ __device__ __forceinline__ void splat_point_wave(const MarkParams& k, const Mark
   });
 }
 
+// block `bi` of the `nb` blocks that undo the dGraph / lethal entries of the markings this update cleared: the first nb_band
+// node by node over the bands, the rest point by point over the points that found no band
+__device__ __forceinline__ void fuse_unmark_block(const MarkParams& k, const FuseBufs& fb, const MarkStore& s, const PointGrid& ground,
+                                                  const MarkCounters* __restrict__ cnt, uint32_t bi, const uint32_t nb, const uint32_t nb_band,
+                                                  const uint32_t seg_groups, const uint32_t n_part, float4* stage) {
+  if (bi < nb_band) {
+    splat_band_block<false>(k, s, ground, fb.rg, fb.unmark_bands, bi / (seg_groups * n_part), (bi / n_part) % seg_groups, bi % n_part, n_part, stage);
+    return;
+  }
+  bi -= nb_band;
+  const uint32_t n_src = cnt->n_unmark_pts;
+  const int lane = threadIdx.x & 63;
+  const uint32_t stride = (nb - nb_band) * 4u;
+  for (uint32_t h = bi * 4u + (threadIdx.x >> 6); h < n_src; h += stride) splat_point_wave<false>(k, s, ground, fb.unmark_pts[h], lane);
+}
+
 // launch 4: seeds  |  removePCPtr of the markings launch 3 cleared: ground node by ground node, and point by point for
 // the points that found no band
 __global__ __launch_bounds__(256) void k_mkf_roots_unmark(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
@@ -588,16 +604,7 @@ __global__ __launch_bounds__(256) void k_mkf_roots_unmark(MarkParams k, FuseBufs
     fuse_roots(k.n_obs, fb.parent, c);
     return;
   }
-  uint32_t bi = blockIdx.x - nb_roots;
-  if (bi < nb_band) {
-    splat_band_block<false>(k, s, ground, fb.rg, fb.unmark_bands, bi / (seg_groups * n_part), (bi / n_part) % seg_groups, bi % n_part, n_part, stage);
-    return;
-  }
-  bi -= nb_band;
-  const uint32_t n_src = cnt->n_unmark_pts;
-  const int lane = threadIdx.x & 63;
-  const uint32_t stride = (gridDim.x - nb_roots - nb_band) * 4u;
-  for (uint32_t h = bi * 4u + (threadIdx.x >> 6); h < n_src; h += stride) splat_point_wave<false>(k, s, ground, fb.unmark_pts[h], lane);
+  fuse_unmark_block(k, fb, s, ground, cnt, blockIdx.x - nb_roots, gridDim.x - nb_roots, nb_band, seg_groups, n_part, stage);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1135,8 +1142,17 @@ __device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBu
 
 // launch 5: 64 partition blocks
 __global__ __launch_bounds__(kPartThreads) void k_mkf_groups(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
-                                                             PointGrid map, uint32_t n_map, MarkCounters* __restrict__ cnt) {
+                                                             PointGrid map, uint32_t n_map, MarkCounters* __restrict__ cnt, uint32_t nb_band,
+                                                             uint32_t seg_groups, uint32_t n_part_un) {
   extern __shared__ __attribute__((aligned(16))) unsigned char fuse_lds[];
+  __shared__ float4 stage[256];
+  if (blockIdx.x >= (uint32_t)kFuseParts) {
+    // removePCPtr of the markings the ray tests cleared, on the CUs the 64 partition workgroups leave idle (it touches the
+    // dGraph and the lethal flags only, the partitions never do; every block of this launch owns the partitions' 140 KB
+    // of LDS, so these run one per CU -- the partitions take 42 us, these are done in 15)
+    fuse_unmark_block(k, fb, s, ground, cnt, blockIdx.x - (uint32_t)kFuseParts, gridDim.x - (uint32_t)kFuseParts, nb_band, seg_groups, n_part_un, stage);
+    return;
+  }
   fuse_partition(k, fb, c, s, ground, map, n_map, cnt, fuse_lds);
 }
 

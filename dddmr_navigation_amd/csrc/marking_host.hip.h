@@ -66,6 +66,7 @@ struct MarkingState {
   hipStream_t cur = nullptr;               // stream of the update in progress
   uint32_t updates_overlapped = 0;
   uint32_t grid_parts = 4;                 // DDDMR_MKF_GRIDPARTS: workgroups that build the observation grid (1, 2, 4, 8)
+  bool unmark_with_groups = true;          // DDDMR_MKF_UNMARK=roots: removePCPtr blocks in the seeds' launch instead of the partitions'
   bool grid_in_lds = true;                 // DDDMR_MKF_GRID=global: counts by launch 1's global atomics instead
   uint32_t unmark_parts = 8;               // DDDMR_MKF_UNPARTS (tuning)
   uint32_t fuse_cells = kFuseMaxCells;     // DDDMR_MKF_CELLS: cells of the fused route's observation grid (tuning)
@@ -393,6 +394,7 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     HIPCHK(ctx, hipMemset(m->counters, 0, sizeof(MarkCounters)));
     HIPCHK(ctx, hipHostMalloc(reinterpret_cast<void**>(&m->host_out), sizeof(MarkCounters), hipHostMallocMapped));
     HIPCHK(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&m->host_out_dev), m->host_out, 0));
+    if (const char* e = std::getenv("DDDMR_MKF_UNMARK")) m->unmark_with_groups = std::strcmp(e, "roots") != 0;
     if (const char* e = std::getenv("DDDMR_MKF_GRIDPARTS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) m->grid_parts = (uint32_t)v; }
     if (const char* e = std::getenv("DDDMR_MKF_GRID")) m->grid_in_lds = std::strcmp(e, "global") != 0;
     if (const char* e = std::getenv("DDDMR_MKF_UNPARTS")) m->unmark_parts = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
@@ -663,6 +665,7 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   if (nb_clear + nb_cc)
     MK_LAUNCH(m, k_mkf_clear_cc, dim3(nb_clear + nb_cc), dim3(256), 0, st, k, s, prev_grid, gb.g, m->ground.g, fb, m->counters, nb_clear);
   if (timed) HIPCHK(ctx, hipEventRecord(m->e1, st));
+  uint32_t nb_un_groups = 0, nb_band_groups = 0;
   // 4: seeds | removePCPtr of the cleared markings: ground node by ground node, point by point for the points that found no band
   {
     // (the removed markings of one update are a tenth of the new generator points: fewer, longer blocks per row)
@@ -671,14 +674,15 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
 #ifdef DDDMR_PHASE_STAMPS
     if (const char* e = std::getenv("DDDMR_MKF_EXP")) { if (std::atoi(e) & 32) nb_un = 0; if (std::atoi(e) & 64) nb_walk = 0; }
 #endif
+    if (mark && m->unmark_with_groups) { nb_un_groups = nb_un + nb_walk; nb_band_groups = nb_un; nb_un = 0; nb_walk = 0; }
     if (nb_roots + nb_un + nb_walk)
       MK_LAUNCH(m, k_mkf_roots_unmark, dim3(nb_roots + nb_un + nb_walk), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters, nb_roots,
                 nb_un, seg_groups, n_part_un);
   }
   // 5: 64 partitions of the clusters
   if (mark)
-    MK_LAUNCH(m, k_mkf_groups, dim3(kFuseParts), dim3(kPartThreads), kPartLdsBytes, st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map,
-              m->counters);
+    MK_LAUNCH(m, k_mkf_groups, dim3(kFuseParts + nb_un_groups), dim3(kPartThreads), kPartLdsBytes, st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map,
+              m->counters, nb_band_groups, seg_groups, m->unmark_parts);
   // 6: keepers -> pool | dGraph of the new generator points (node by node); the last block publishes the counters
   {
     uint32_t nb_commit = mark ? (n_obs + 255) / 256 : 0, nb_b = mark ? nb_band : 0u, nb_walk = mark ? 256u : 1u;
