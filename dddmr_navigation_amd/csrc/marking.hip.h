@@ -75,6 +75,36 @@ __device__ __forceinline__ void grid_for_each(const PointGrid& g, float qx, floa
   const int x0 = grid_cx(g, qx - r), x1 = grid_cx(g, qx + r);
   const int y0 = grid_cy(g, qy - r), y1 = grid_cy(g, qy + r);
   const int z0 = grid_cz(g, qz - r), z1 = grid_cz(g, qz + r);
+  const int nys = y1 - y0 + 1, nrows = nys * (z1 - z0 + 1);
+  if (nrows <= 4 && nys <= 2) {
+    // The usual case (a ball no wider than a cell: at most 2 x 2 rows of cells): the bounds of all rows and the first point
+    // of each are loaded together, then walked in the same order -- two dependent round trips per query instead of two
+    // per row (the ray tests and the "still observed" test are chains of these).
+    uint32_t b[4], e[4];
+    float4 first[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int q = min(rr, nrows - 1);
+      const int cz = z0 + (nys == 2 ? (q >> 1) : q), cy = y0 + (nys == 2 ? (q & 1) : 0);
+      const int row = (cz * g.ny + cy) * g.nx;
+      b[rr] = g.cell_start[row + x0];
+      e[rr] = g.cell_start[row + x1 + 1];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      if (rr >= nrows) e[rr] = b[rr];
+      first[rr] = b[rr] < e[rr] ? g.sorted[b[rr]] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      if (b[rr] < e[rr]) {
+        if (f(first[rr])) return;
+        for (uint32_t k = b[rr] + 1u; k < e[rr]; ++k)
+          if (f(g.sorted[k])) return;
+      }
+    }
+    return;
+  }
   for (int cz = z0; cz <= z1; ++cz)
     for (int cy = y0; cy <= y1; ++cy) {
       const uint32_t b = g.cell_start[(cz * g.ny + cy) * g.nx + x0], e = g.cell_start[(cz * g.ny + cy) * g.nx + x1 + 1];
@@ -224,7 +254,12 @@ __global__ __launch_bounds__(256) void k_mk_fov(MarkParams k, MarkStore s, MarkC
 }
 
 #ifdef DDDMR_PHASE_STAMPS
-__device__ unsigned long long g_mk_clear_cyc[8];   // diagnostic build: [0] rays, [1] chunks probed, cycles of [2] phase A, [3] phase B, [4] near test, [5] removal
+__device__ int g_mk_exp_noprobe;                    // diagnostic build: 1 = the ray probes look nothing up (wrong results: timing only)
+#endif
+// -DDDDMR_CLEAR_CYCLES (on top of the diagnostic build): per-ray cycle sums -- their same-address atomics make the launch
+// itself ~20x slower, so they are only good for shares, never next to kernel times
+#ifdef DDDMR_CLEAR_CYCLES
+__device__ unsigned long long g_mk_clear_cyc[8];   // [0] rays, [1] chunks probed, cycles of [2] phase A, [3] phase B, [4] near test, [5] removal
 #define MKC_NOW() clock64()
 #define MKC_ADD(i, v) do { if (lane == 0) atomicAdd(&g_mk_clear_cyc[i], (unsigned long long)(v)); } while (0)
 #else
@@ -258,12 +293,13 @@ __device__ __forceinline__ bool mk_clear_wave(const MarkParams& k, const MarkSto
       // The reference's running float sum t += dt: lane i holds the i-th partial sum.  One chain for the wave: every step
       // each lane takes its left neighbour's value + dt (DPP wave_shr:1) and lane 0 is put back to t0, so after 63 steps
       // lane i has been through exactly i additions, in order.
+      // (one instruction per step: v_add_f32_dpp with bound_ctrl off leaves lane 0, which has no left neighbour, unwritten;
+      // the compiler's form of the same chain needs a v_cndmask per step to put t0 back.  s_nop 1: the two wait states a
+      // DPP read of a VGPR written by the previous VALU instruction needs.)
       float t = t0;
 #pragma unroll
-      for (int j = 0; j < 63; ++j) {
-        const float left = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(t), 0x138, 0xF, 0xF, false));
-        t = lane == 0 ? t0 : left + dt;
-      }
+      for (int j = 0; j < 63; ++j)
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(t) : "v"(dt));
       const bool live = t <= 1.0;
       bool stop = false, hit = false;
       if (live) {
@@ -282,6 +318,9 @@ __device__ __forceinline__ bool mk_clear_wave(const MarkParams& k, const MarkSto
         }
         if (!stop) {
           const float r2 = static_cast<float>(sd * sd);
+#ifdef DDDMR_PHASE_STAMPS
+          if (!g_mk_exp_noprobe)
+#endif
           hit = grid_radius_count(prev, ax, ay, az, (float)sd + 1e-4f, r2, 1) > 0;
         }
       }

@@ -799,15 +799,15 @@ __device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBu
     const uint32_t chunk = (((n + 3u) / 4u) + 63u) & ~63u;
     const uint32_t lo = min((uint32_t)w * chunk, n), hi = min(lo + chunk, n);
     uint32_t have = 0;
-    for (uint32_t i0 = lo; i0 < hi; i0 += 64u * 8u) {
-      uint32_t r[8];
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64u * 32u) {         // (32 loads in flight: a wave's quarter of 10 k seeds in two trips)
+      uint32_t r[32];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 32; ++u) {
         const uint32_t i = i0 + 64u * u + lane;
         r[u] = i < hi ? fb.parent[i] : 0xFFFFFFFFu;
       }
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
+      for (int u = 0; u < 32; ++u) {
         const uint32_t i = i0 + 64u * u + lane;
         const bool sel = r[u] != 0xFFFFFFFFu && part_of(r[u]) == part;
         const unsigned long long b = __ballot(sel);

@@ -656,6 +656,9 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
     const uint32_t nb_grid = mark ? (m->grid_in_lds ? m->grid_parts : 1u) : 0u;
     MK_LAUNCH(m, k_mkf_grid_fov, dim3(nb_grid + (m->table + 1023) / 1024), dim3(1024), 0, st, k, s, gb.g, fb, m->counters, nb_grid);
   }
+#ifdef DDDMR_PHASE_STAMPS
+  if (const char* e = std::getenv("DDDMR_MKF_EXP")) { const int v = (std::atoi(e) & 128) ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(dddmr::g_mk_exp_noprobe), &v, sizeof(v)); }
+#endif
   // 3: ray tests | union-find
   uint32_t nb_clear = (n_alive + 3) / 4, nb_cc = mark ? (n_obs * 4 + 255) / 256 : 0;
 #ifdef DDDMR_PHASE_STAMPS
@@ -878,7 +881,12 @@ int dddmr_rollout_diag_mkstamps(unsigned long long* out, size_t n_words) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(dddmr::g_mk_stamps), n_words * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 int dddmr_rollout_diag_mkclear(unsigned long long* out) {
+#ifdef DDDMR_CLEAR_CYCLES
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(dddmr::g_mk_clear_cyc), 8 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+#else
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  return 0;
+#endif
 }
 #endif
 
