@@ -58,6 +58,29 @@ inline int feedScan(
   return rc;
 }
 
+// The same for plugin number `source` of several sensor plugins (its position in perception_3d's `plugins:` list,
+// 0 .. DDDMR_MAX_SOURCES - 1): the device keeps one feed per source and publishes their concatenation in source order,
+// which is StackedPerception::aggregateObservations (src/stacked_perception.cpp:128-140).
+template<class Cloud, class TransformStamped>
+inline int feedScanSource(
+  dddmr_rollout_ctx * ctx, int source, const Cloud & scan_sensor_frame, const TransformStamped & trans_b2s,
+  const TransformStamped & trans_gbl2b, double perception_window_size, double marking_height, int stitcher_num,
+  uint32_t * n_source_out = nullptr, uint32_t * n_aggregate_out = nullptr)
+{
+  if (!ctx) {return DDDMR_ERR_BAD_ARG;}
+  double b2s[7], g2b[7];
+  toPose7(trans_b2s, b2s);
+  toPose7(trans_gbl2b, g2b);
+  int rc = dddmr_rollout_set_stitcher_source(ctx, source, stitcher_num > 0 ? stitcher_num : 0);
+  if (rc != DDDMR_OK) {return rc;}
+  const size_t n = scan_sensor_frame.points.size();
+  rc = dddmr_rollout_set_scan_source(
+    ctx, source, n ? &scan_sensor_frame.points[0].x : nullptr, n, sizeof(scan_sensor_frame.points[0]), b2s, g2b,
+    perception_window_size, marking_height, n_source_out, n_aggregate_out);
+  if (rc == DDDMR_OK) {SharedContext::noteDeviceFeed();}
+  return rc;
+}
+
 // PathBlockedStrategy::selfMark on the device's aggregate observation.  pcl_prune_plan is
 // shared_data_->pcl_prune_plan_ (pcl::PointXYZI, 32-byte records: repacked to x y z intensity).
 template<class PlanCloud>

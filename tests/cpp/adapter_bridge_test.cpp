@@ -57,6 +57,10 @@ int dddmr_rollout_get_best_poses(dddmr_rollout_ctx*, double* out, size_t cap, si
 int dddmr_rollout_set_stitcher(dddmr_rollout_ctx*, int32_t n) { F.stitcher = n; return DDDMR_OK; }
 int dddmr_rollout_set_scan(dddmr_rollout_ctx*, const float*, size_t n, size_t stride, const double b2s[7], const double g2b[7], double, double, uint32_t* n_out) {
   ++F.n_scan; F.scan_n = n; F.scan_stride = stride; assert(b2s[6] == 1.0 && g2b[0] == 2.0); if (n_out) *n_out = 7; return F.rc_scan; }
+int dddmr_rollout_set_stitcher_source(dddmr_rollout_ctx*, int32_t src, int32_t n) { F.stitcher = 100 * src + n; return src >= 0 && src < DDDMR_MAX_SOURCES ? DDDMR_OK : DDDMR_ERR_BAD_ARG; }
+int dddmr_rollout_set_scan_source(dddmr_rollout_ctx*, int32_t src, const float*, size_t n, size_t stride, const double b2s[7], const double g2b[7], double, double,
+                                  uint32_t* n_src, uint32_t* n_all) {
+  ++F.n_scan; F.scan_n = n; F.scan_stride = stride; assert(src == 1 && b2s[6] == 1.0 && g2b[0] == 2.0); if (n_src) *n_src = 7; if (n_all) *n_all = 19; return F.rc_scan; }
 int dddmr_rollout_path_blocked(dddmr_rollout_ctx*, const float* p, size_t n, double r, double* ratio, int32_t* opinion, uint8_t*) {
   F.pb.assign(p, p + 4 * n); F.check_radius = r; *ratio = 25.0; *opinion = DDDMR_OPINION_PATH_BLOCKED_WAIT; return DDDMR_OK; }
 int dddmr_rollout_marking_create(dddmr_rollout_ctx*, const dddmr_marking_config*, const float*, size_t, size_t gs, const float*, size_t, size_t) {
@@ -130,6 +134,16 @@ int main() {
   assert(F.n_set_cloud == before + 1);
   F.rc_scan = DDDMR_ERR_CAPACITY;                                    // a failed feed does not claim the cycle
   assert(feedScan(&ctx, scan, b2s, g2b, 5.0, 2.0, 0) == DDDMR_ERR_CAPACITY && F.stitcher == 0);
+  {                                                                      // a second sensor plugin: source 1
+    const int rc_was = F.rc_scan, scans_was = F.n_scan;
+    F.rc_scan = DDDMR_OK;
+    uint32_t n_src = 0, n_all = 0;
+    assert(feedScanSource(&ctx, 1, scan, b2s, g2b, 5.0, 2.0, 3, &n_src, &n_all) == DDDMR_OK);
+    assert(F.n_scan == scans_was + 1 && F.stitcher == 103 && n_src == 7 && n_all == 19);
+    assert(feedScanSource(&ctx, DDDMR_MAX_SOURCES, scan, b2s, g2b, 5.0, 2.0, 0) == DDDMR_ERR_BAD_ARG && F.n_scan == scans_was + 1);
+    (void)SharedContext::consumeDeviceFeed();
+    F.rc_scan = rc_was;
+  }
   before = F.n_set_cloud;
   (void)rolloutTick(&ctx, obs, plan, g2b, odom, 0.8, 0.25, "t", best, &res, &err);
   assert(F.n_set_cloud == before + 1);
