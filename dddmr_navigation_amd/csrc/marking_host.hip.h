@@ -68,6 +68,7 @@ struct MarkingState {
   uint32_t grid_parts = 4;                 // DDDMR_MKF_GRIDPARTS: workgroups that build the observation grid (1, 2, 4, 8)
   bool unmark_with_groups = true;          // DDDMR_MKF_UNMARK=roots: removePCPtr blocks in the seeds' launch instead of the partitions'
   bool grid_in_lds = true;                 // DDDMR_MKF_GRID=global: counts by launch 1's global atomics instead
+  uint32_t splat_parts = 0;                // DDDMR_MKF_PARTS: blocks that share a row segment's bands in the commit launch (0: estimated)
   uint32_t unmark_parts = 8;               // DDDMR_MKF_UNPARTS (tuning)
   uint32_t fuse_cells = kFuseMaxCells;     // DDDMR_MKF_CELLS: cells of the fused route's observation grid (tuning)
 };
@@ -397,6 +398,7 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     if (const char* e = std::getenv("DDDMR_MKF_UNMARK")) m->unmark_with_groups = std::strcmp(e, "roots") != 0;
     if (const char* e = std::getenv("DDDMR_MKF_GRIDPARTS")) { const int v = std::atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) m->grid_parts = (uint32_t)v; }
     if (const char* e = std::getenv("DDDMR_MKF_GRID")) m->grid_in_lds = std::strcmp(e, "global") != 0;
+    if (const char* e = std::getenv("DDDMR_MKF_PARTS")) m->splat_parts = (uint32_t)std::min(128, std::max(0, std::atoi(e)));
     if (const char* e = std::getenv("DDDMR_MKF_UNPARTS")) m->unmark_parts = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (const char* e = std::getenv("DDDMR_MKF_CELLS")) m->fuse_cells = std::min<uint32_t>(kFuseMaxCells, std::max(4096, std::atoi(e)));
     if (const char* e = std::getenv("DDDMR_MARKING_ROUTE")) m->route = std::strcmp(e, "general") == 0 ? 0 : (std::strcmp(e, "fused") == 0 ? 1 : -1);
@@ -647,7 +649,20 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   FuseBufs fb{obs, m->parent, m->ds, m->gen, m->clear_list, m->unmark_pts,
               BandList{m->band_pts, m->band_cnt}, BandList{m->band_pts + (size_t)kBandMax * kBandCap, m->band_cnt + kBandMax}, rg,
               m->ticket, m->cell_count, m->keys_a, m->host_out_dev, m->grid_in_lds ? 1u : 0u};
-  const uint32_t seg_groups = (rg.segs + 3u) / 4u, n_part = 48u;
+  // Blocks that share one row segment's bands in the commit launch: a block takes every n_part-th 256-point chunk of the
+  // 2 delta + 1 bands in reach, so more blocks than chunks only add blocks that read the band counts and leave (measured at
+  // C5M, ~110 points per band, 9 bands in reach: n_part 48 / 24 / 16 / 12 / 8 -> mark phase 80 / 68 / 68 / 66 / 67 us).
+  // Estimated from the observation size (at most one generator point per observation point, about half in practice).
+  uint32_t n_part = m->splat_parts;
+  if (n_part == 0) {
+    const uint32_t per_band = std::max(1u, n_obs / 2u / std::max(1u, rg.bands));
+    const uint32_t chunks = (2u * (uint32_t)rg.delta + 1u) * ((per_band + 255u) / 256u);
+    n_part = std::min(48u, std::max(8u, chunks + chunks / 3u));
+  }
+  const uint32_t seg_groups = (rg.segs + 3u) / 4u;
+  if (m->seq == 3 && std::getenv("DDDMR_DEBUG_GRID"))
+    std::fprintf(stderr, "[dddmr] marking update: %u points, %u alive; window rows %u x %u segments, %u bands, delta %d -> %u blocks per row segment\n",
+                 n_obs, m->n_alive_host, rg.rows, rg.segs, rg.bands, rg.delta, n_part);
   const uint32_t nb_band = rg.bands ? rg.rows * seg_groups * n_part : 0u;
   // 1: cell counts of the observation grid
   if (mark && !m->grid_in_lds) MK_LAUNCH(m, k_mkf_count, dim3((n_obs + 255) / 256), dim3(256), 0, st, gb.g, fb);
