@@ -721,7 +721,7 @@ def main():
             upd_ms = ms["clear_ms"] + ms["mark_ms"]
             b_upd = (4 * 16 + 8 + 4) * n_obs + 2 * 4 * 65536 + 32 * ms["alive_markings"] + 2 * 32 * int(ms["marked_per_update"] * 1.3) + 25 * 8000
             out["roofline_marking"] = {
-                "bound": "hbm", "kernel": "marking update (6 launches: k_mkf_*)", "achieved": round(b_upd / (upd_ms * 1e-3) / 1e9, 2) if upd_ms > 0 else None,
+                "bound": "hbm", "kernel": "marking update (5 launches: k_mkf_*)", "achieved": round(b_upd / (upd_ms * 1e-3) / 1e9, 2) if upd_ms > 0 else None,
                 "peak": 8000.0, "unit": "GB/s", "frac": round(b_upd / (upd_ms * 1e-3) / 8.0e12, 5) if upd_ms > 0 else None,
                 "bytes_per_update": b_upd, "update_ms": round(upd_ms, 5), "traffic": None,
                 "what_binds_it": {"name": "dependent-latency chains and instruction issue (ray marches, union-find, 64 one-workgroup partitions), "
