@@ -437,6 +437,10 @@ typedef struct {
 int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_config* cfg,
                                  const float* ground_xyz, size_t n_ground, size_t ground_stride_bytes,
                                  const float* map_xyz, size_t n_map, size_t map_stride_bytes);
+/* One doClear_then_Mark pass.  May be called between dddmr_rollout_tick_begin and _tick_end: the
+   reference runs the perception thread's pass and the planner's tick side by side, and so does the
+   device (the update takes a stream of its own next to the tick's kernels) -- provided no newer
+   observation was published after tick_begin, else DDDMR_ERR_STATE (call it after tick_end). */
 int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sensor[7],
                                  const double T_gbl_base[7], dddmr_marking_stats* stats);
 /* resetdGraph: empty store, dGraph back to max_obstacle_distance. */
