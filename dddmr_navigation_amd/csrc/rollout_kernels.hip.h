@@ -1188,30 +1188,6 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
   for (int j = 0; j < tile; ++j) nt += ((tb < k.nb_tiles || j + k.r0 < tile) && tile_slot(k, tb, j) < k.n_local) ? 1 : 0;
 
   DDDMR_STAMP(0);
-  // ---- rollout state of this lane's pair, fetched BEFORE the headers are in ----
-  // A workgroup's life is mostly dependent round trips to L2 (assignment -> header -> rollout state -> points ...: the
-  // fixed ~13 us a tile costs whatever its size).  The state rows are max_steps long whatever a trajectory's step count,
-  // so lane (j, s) of the DENSE tile x max_steps layout can load its state as soon as it knows trajectory j's row --
-  // one trip after the assignment instead of one after the header; D1 then runs on the dense layout (a lane whose step
-  // does not exist idles) and files its results at the compact pair index as before.  Only when the dense layout fits
-  // the lanes (every multi-round shape; single-round tiles of up to two pairs per lane keep the compact loop).
-  const bool dense_pf = tile * k.max_steps <= kScoreThreads;
-  int pf_j = 0, pf_s = 0;
-  bool pf_ok = false;
-  double2 pf_cs = make_double2(0.0, 0.0);
-  float2 pf_xy = make_float2(0.f, 0.f);
-  if (dense_pf && tid < tile * k.max_steps) {
-    pf_j = tid / k.max_steps;
-    pf_s = tid - pf_j * k.max_steps;
-    if (pf_j < nt) {                                           // (the valid slots of a tile are its first nt)
-      const int slot = tile_slot(k, tb, pf_j);
-      const int li = k.use_assign ? (int)assign[slot] : slot;
-      const size_t so = (size_t)li * k.max_steps + pf_s;
-      pf_cs = st_sc[so];
-      pf_xy = st_xy[so];
-      pf_ok = true;
-    }
-  }
   // ---- stage the prune plan (float xyz, model_shared_data.h:83-91) ----
   for (int i = tid; i < k.m; i += kScoreThreads) plan[i] = plan_xyz[i];
 
@@ -1230,15 +1206,6 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
     h.pp_dist = 0.0; h.pp_yaw = 0.0; h.stick_sum = 0.0;
     h.li = li;
     h.walked = 0;
-    if (ti.steps > 0) {
-      // the state of the LAST pose (pure pursuit, after D1) is asked for now and parked in the fields pure pursuit and
-      // StickPath fill later: its round trip runs under D1 instead of after it
-      const size_t so = (size_t)li * k.max_steps + (ti.steps - 1);
-      const double2 cs = st_sc[so];
-      const float2 bxy = st_xy[so];
-      h.pp_dist = cs.x; h.pp_yaw = cs.y;
-      h.stick_sum = __hiloint2double(__float_as_int(bxy.y), __float_as_int(bxy.x));
-    }
     head[tid] = h;
   }
   // the costmap's row-run index is staged meanwhile (independent loads)
@@ -1263,24 +1230,13 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
   if (nt > 0) total_pairs = head[nt - 1].pair_base + head[nt - 1].steps;
   const bool cloud_ok = k.n_points >= 5;   // collision_model.cpp:53-55
   const bool do_coll = cloud_ok && (need_box || need_mm);
-  for (int qq = tid; qq < (dense_pf ? kScoreThreads : total_pairs); qq += kScoreThreads) {
-    int j, s, q;
-    double2 cs;                                      // heading after the step
-    float2 bxy;                                      // body-frame position after the step
-    if (dense_pf) {
-      j = pf_j; s = pf_s;
-      if (!pf_ok || s >= head[j].steps) continue;
-      q = head[j].pair_base + s;
-      cs = pf_cs; bxy = pf_xy;
-    } else {
-      q = qq;
-      j = 0;
-      while (j + 1 < nt && head[j + 1].pair_base <= q) ++j;
-      s = q - head[j].pair_base;
-      const size_t so = (size_t)head[j].li * k.max_steps + s;
-      cs = st_sc[so];
-      bxy = st_xy[so];
-    }
+  for (int q = tid; q < total_pairs; q += kScoreThreads) {
+    int j = 0;
+    while (j + 1 < nt && head[j + 1].pair_base <= q) ++j;
+    const int s = q - head[j].pair_base;
+    const size_t so = (size_t)head[j].li * k.max_steps + s;
+    const double2 cs = st_sc[so];                    // heading after the step
+    const float2 bxy = st_xy[so];                    // body-frame position after the step
     const double c = cs.x, sn = cs.y;
     // trans_gbl2traj = pos_af3 * [Rz(theta), (x, y, 0)]
     double L[9], T[3];
@@ -1434,9 +1390,9 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
   // trajectory, after the pair loop so that only one wave pays for the atan2 ----
   if (tid < nt && head[tid].steps > 0) {
     const int j = tid;
-    const double2 cs = make_double2(head[j].pp_dist, head[j].pp_yaw);       // (parked by phase A)
-    const float2 bxy = make_float2(__int_as_float(__double2loint(head[j].stick_sum)), __int_as_float(__double2hiint(head[j].stick_sum)));
-    head[j].stick_sum = 0.0;
+    const size_t so = (size_t)head[j].li * k.max_steps + (head[j].steps - 1);
+    const double2 cs = st_sc[so];
+    const float2 bxy = st_xy[so];
     const double c = cs.x, sn = cs.y;
     double L[9], T[3];
 #pragma unroll
