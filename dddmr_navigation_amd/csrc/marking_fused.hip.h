@@ -1,22 +1,26 @@
-// marking_fused.hip.h -- the marking / clearing update for observations of up to 16384 points in SIX launches.
+// marking_fused.hip.h -- the marking / clearing update for observations of up to 16384 points in FIVE launches.
 //
-// The general route (marking.hip.h + rocPRIM sorts, any observation size) issues ~55 launches per update, ~30 of them
+// The general route (marking.hip.h + rocPRIM sorts, any observation size) issues ~60 launches per update, ~30 of them
 // at the 4.5-4.9 us launch floor, plus three mid-update copies: for the observation of a 16-line LiDAR the update is
 // launch-bound (profiles/r02_C5M_kernel_stats.csv).  Here the chip-wide steps share launches, and everything between
 // the union-find and the dGraph update -- three stable sorts with their flag / scan / reduce rounds, the per-cluster
 // tests, the hash insert -- runs in 64 independent 256-lane workgroups, each on the clusters whose seed point hashes
 // to it, with points, sort keys and payloads resident in LDS:
 //
-//   launch 1  k_mkf_count           cell counts of the new observation's grid
-//   launch 2  k_mkf_grid_fov        block 0: scan of the cell counts in LDS, scatter  |  every store slot: window +
-//                                   field-of-view test -> list of ray tests
-//   launch 3  k_mkf_clear_cc        selfClear ray tests (a wave per listed marking)  |  Euclidean clustering (union-find)
-//   launch 4  k_mkf_roots_unmark    every point's cluster seed (root of the union-find)  |  removePCPtr of the markings
-//                                   launch 3 cleared, ground node by ground node
-//   launch 5  k_mkf_groups          64 blocks, partition p = clusters with hash(seed) = p: centroids -> 0.2 m VoxelGrid
-//                                   -> static / FOV tests -> projection + 0.1 m VoxelGrid -> store slots
-//   launch 6  k_mkf_commit_dgraph   keeper of every claimed voxel -> pool  |  dGraph / lethal update, ground node by
-//                                   ground node; the last block publishes the counters to host-mapped memory
+//   grid launch       k_mkf_grid_fov        first blocks: the new observation's uniform grid, built in LDS from the points
+//                                           alone (a quarter of the cells per workgroup)  |  every store slot: window +
+//                                           field-of-view test -> list of ray tests
+//   clear launch      k_mkf_clear_cc        selfClear ray tests (a wave per listed marking)  |  Euclidean clustering
+//                                           (union-find)
+//   seed launch       k_mkf_roots_unmark    every point's cluster seed (root of the union-find)
+//   partition launch  k_mkf_groups          64 blocks, partition p = clusters with hash(seed) = p: centroids -> 0.2 m
+//                                           VoxelGrid -> static / FOV tests -> projection + 0.1 m VoxelGrid -> store
+//                                           slots  |  on the idle CUs: removePCPtr of the markings the clear launch
+//                                           removed, ground node by ground node
+//   commit launch     k_mkf_commit_dgraph   keeper of every claimed voxel -> pool  |  dGraph / lethal update, ground node
+//                                           by ground node; the last block publishes the counters to host-mapped memory
+//   (DDDMR_MKF_GRID=global: a sixth launch, k_mkf_count, counts the cells with global atomics first;
+//    DDDMR_MKF_UNMARK=roots: removePCPtr in the seed launch)
 //
 // (A first version ran the grouping chain in ONE 1024-lane workgroup with the keys in registers: 670 us at 10.5 k
 // points -- a wave64 VALU instruction occupies its SIMD for four cycles and one CU is 1/256 of the chip; the phase
@@ -140,9 +144,9 @@ __device__ __forceinline__ void project_on_base_plane(const MarkParams& k, float
 }
 
 // ---------------------------------------------------------------------------------------------
-// launches 1 + 2: uniform grid of the observation (<= 16384 points, <= 65536 cells).  The blocks of launch 1 count 256
+// count + grid launch (DDDMR_MKF_GRID=global): uniform grid of the observation (<= 16384 points, <= 65536 cells).  The blocks of the count launch take 256
 // points each into the cells (device-scope atomics: the rank inside the cell comes back) and leave (cell, rank) per point;
-// launch 2, one workgroup, scans the counters in LDS (16 bits each, two per word), writes the cell starts, leaves the
+// the grid launch's first workgroup scans the counters in LDS (16 bits each, two per word), writes the cell starts, leaves the
 // counters zeroed for the next update and scatters the points.  (As the last-ticket block of launch 1 the scan had to
 // read the counters past its XCD's L2, one sc1 load after the other: 60 us; built in LDS by one workgroup from scratch,
 // count included: 41 us.)  The order of the points inside a cell is whatever the atomics made it: no result depends on
@@ -304,10 +308,10 @@ __device__ __forceinline__ void fuse_grid_build_lds(const PointGrid& g, const fl
   MKF_STAMP(35);
 }
 
-// launch 1: cell counts
+// count launch (DDDMR_MKF_GRID=global only): cell counts
 __global__ __launch_bounds__(256) void k_mkf_count(PointGrid obs, FuseBufs fb) { fuse_grid_count(obs, fb.pts, fb.parent, fb.cell_count, fb.slot); }
 
-// launch 2: block 0: scan + scatter of the observation grid (one workgroup)  |  blocks 1..: every slot of the store
+// grid launch: first blocks: the observation grid  |  the others: every slot of the store
 __global__ __launch_bounds__(1024) void k_mkf_grid_fov(MarkParams k, MarkStore s, PointGrid obs, FuseBufs fb, MarkCounters* __restrict__ cnt,
                                                        uint32_t nb_grid) {
   __shared__ uint32_t cnt2[33 * 1024];
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(1024) void k_mkf_grid_fov(MarkParams k, MarkStore s
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 3: selfClear (a wave per listed marking)  |  Euclidean clustering, four lanes per point
+// clear launch: selfClear (a wave per listed marking)  |  Euclidean clustering, four lanes per point
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void cc_union_pair(uint32_t* parent, uint32_t i, uint32_t j) {
   uint32_t u = cc_find(parent, i), v = cc_find(parent, j);
@@ -424,7 +428,7 @@ __global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s,
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 4: every point's seed (the smallest point index of its component = the point PCL starts the cluster from);
+// seed launch: every point's seed (the smallest point index of its component = the point PCL starts the cluster from);
 // the per-cluster records of every point index start empty (a cluster is named by its seed's index)
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void fuse_roots(uint32_t n, uint32_t* parent, ClusterArrays c) {
@@ -594,7 +598,7 @@ __device__ __forceinline__ void fuse_unmark_block(const MarkParams& k, const Fus
   for (uint32_t h = bi * 4u + (threadIdx.x >> 6); h < n_src; h += stride) splat_point_wave<false>(k, s, ground, fb.unmark_pts[h], lane);
 }
 
-// launch 4: seeds  |  removePCPtr of the markings launch 3 cleared: ground node by ground node, and point by point for
+// seed launch: seeds  |  (DDDMR_MKF_UNMARK=roots, or nothing to mark) removePCPtr of the markings the clear launch removed: ground node by ground node, and point by point for
 // the points that found no band
 __global__ __launch_bounds__(256) void k_mkf_roots_unmark(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
                                                           const MarkCounters* __restrict__ cnt, uint32_t nb_roots, uint32_t nb_band,
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(256) void k_mkf_roots_unmark(MarkParams k, FuseBufs
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 5, blocks 0..63: one partition of the clusters, everything in LDS
+// partition launch, blocks 0..63: one partition of the clusters, everything in LDS
 // ---------------------------------------------------------------------------------------------
 struct PartLds {              // carve-up of the dynamic LDS of a partition workgroup
   float *px, *py, *pz;        // [P] the partition's points (index order); second half: projected 0.2 m voxel centroids
@@ -1140,7 +1144,7 @@ __device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBu
 #endif
 }
 
-// launch 5: 64 partition blocks
+// partition launch: 64 partition blocks  |  removePCPtr blocks
 __global__ __launch_bounds__(kPartThreads) void k_mkf_groups(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,
                                                              PointGrid map, uint32_t n_map, MarkCounters* __restrict__ cnt, uint32_t nb_band,
                                                              uint32_t seg_groups, uint32_t n_part_un) {
@@ -1157,7 +1161,7 @@ __global__ __launch_bounds__(kPartThreads) void k_mkf_groups(MarkParams k, FuseB
 }
 
 // ---------------------------------------------------------------------------------------------
-// launch 6: the keeper of every claimed voxel stores its generator points (k_mk_commit)  |  dGraph / lethal update of
+// commit launch: the keeper of every claimed voxel stores its generator points (k_mk_commit)  |  dGraph / lethal update of
 // the new generator points (k_mk_dgraph); the last block to finish publishes the counters and leaves them zeroed
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mkf_commit_dgraph(MarkParams k, FuseBufs fb, ClusterArrays c, MarkStore s, PointGrid ground,

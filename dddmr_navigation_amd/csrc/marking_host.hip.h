@@ -664,9 +664,9 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
     std::fprintf(stderr, "[dddmr] marking update: %u points, %u alive; window rows %u x %u segments, %u bands, delta %d -> %u blocks per row segment\n",
                  n_obs, m->n_alive_host, rg.rows, rg.segs, rg.bands, rg.delta, n_part);
   const uint32_t nb_band = rg.bands ? rg.rows * seg_groups * n_part : 0u;
-  // 1: cell counts of the observation grid
+  // (DDDMR_MKF_GRID=global only) cell counts of the observation grid
   if (mark && !m->grid_in_lds) MK_LAUNCH(m, k_mkf_count, dim3((n_obs + 255) / 256), dim3(256), 0, st, gb.g, fb);
-  // 2: scan + scatter of the observation grid (one workgroup) | every store slot: window + FOV test -> ray-test list
+  // grid launch: the observation grid (built in LDS by the first grid_parts workgroups) | every store slot: window + FOV test -> ray-test list
   {
     const uint32_t nb_grid = mark ? (m->grid_in_lds ? m->grid_parts : 1u) : 0u;
     MK_LAUNCH(m, k_mkf_grid_fov, dim3(nb_grid + (m->table + 1023) / 1024), dim3(1024), 0, st, k, s, gb.g, fb, m->counters, nb_grid);
@@ -674,7 +674,7 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
 #ifdef DDDMR_PHASE_STAMPS
   if (const char* e = std::getenv("DDDMR_MKF_EXP")) { const int v = (std::atoi(e) & 128) ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(dddmr::g_mk_exp_noprobe), &v, sizeof(v)); }
 #endif
-  // 3: ray tests | union-find
+  // clear launch: ray tests | union-find
   uint32_t nb_clear = (n_alive + 3) / 4, nb_cc = mark ? (n_obs * 4 + 255) / 256 : 0;
 #ifdef DDDMR_PHASE_STAMPS
   // diagnostic build only (results are wrong with either): time the two halves of the launch apart
@@ -684,7 +684,7 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
     MK_LAUNCH(m, k_mkf_clear_cc, dim3(nb_clear + nb_cc), dim3(256), 0, st, k, s, prev_grid, gb.g, m->ground.g, fb, m->counters, nb_clear);
   if (timed) HIPCHK(ctx, hipEventRecord(m->e1, st));
   uint32_t nb_un_groups = 0, nb_band_groups = 0;
-  // 4: seeds | removePCPtr of the cleared markings: ground node by ground node, point by point for the points that found no band
+  // seed launch: seeds (| removePCPtr of the cleared markings when it does not ride in the partition launch)
   {
     // (the removed markings of one update are a tenth of the new generator points: fewer, longer blocks per row)
     const uint32_t n_part_un = m->unmark_parts;
@@ -697,11 +697,11 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
       MK_LAUNCH(m, k_mkf_roots_unmark, dim3(nb_roots + nb_un + nb_walk), dim3(256), 0, st, k, fb, m->cl, s, m->ground.g, m->counters, nb_roots,
                 nb_un, seg_groups, n_part_un);
   }
-  // 5: 64 partitions of the clusters
+  // partition launch: 64 partitions of the clusters | removePCPtr: ground node by ground node, point by point for the points that found no band
   if (mark)
     MK_LAUNCH(m, k_mkf_groups, dim3(kFuseParts + nb_un_groups), dim3(kPartThreads), kPartLdsBytes, st, k, fb, m->cl, s, m->ground.g, m->map.g, m->n_map,
               m->counters, nb_band_groups, seg_groups, m->unmark_parts);
-  // 6: keepers -> pool | dGraph of the new generator points (node by node); the last block publishes the counters
+  // commit launch: keepers -> pool | dGraph of the new generator points (node by node); the last block publishes the counters
   {
     uint32_t nb_commit = mark ? (n_obs + 255) / 256 : 0, nb_b = mark ? nb_band : 0u, nb_walk = mark ? 256u : 1u;
 #ifdef DDDMR_PHASE_STAMPS

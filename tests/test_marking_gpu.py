@@ -35,7 +35,7 @@ def _vset(v):
 
 @pytest.fixture(autouse=True, params=["fused", "general"])
 def route(request, monkeypatch):
-    """Every test runs on both routes of dddmr_rollout_marking_update: `fused` (four launches, observations of up to
+    """Every test runs on both routes of dddmr_rollout_marking_update: `fused` (five launches, observations of up to
     16384 points: csrc/marking_fused.hip.h) and `general` (library sorts, any size: csrc/marking.hip.h).  The layer
     reads DDDMR_MARKING_ROUTE when it is created."""
     monkeypatch.setenv("DDDMR_MARKING_ROUTE", request.param)
