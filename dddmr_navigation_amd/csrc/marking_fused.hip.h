@@ -94,7 +94,7 @@ struct FuseBufs {
   uint32_t* cell_count;    // [kFuseMaxCells] all zero between updates
   unsigned long long* slot;  // [n] (rank << 32) | cell of a point in the observation grid
   MarkCounters* host_out;  // host-mapped copy of the update's counters
-  uint32_t grid_in_lds;    // the observation grid is built by launch 2's first workgroups alone (no launch 1)
+  uint32_t grid_in_lds;    // the observation grid is built by the grid launch's first workgroups alone (no count launch)
 };
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
@@ -147,7 +147,7 @@ __device__ __forceinline__ void project_on_base_plane(const MarkParams& k, float
 // count + grid launch (DDDMR_MKF_GRID=global): uniform grid of the observation (<= 16384 points, <= 65536 cells).  The blocks of the count launch take 256
 // points each into the cells (device-scope atomics: the rank inside the cell comes back) and leave (cell, rank) per point;
 // the grid launch's first workgroup scans the counters in LDS (16 bits each, two per word), writes the cell starts, leaves the
-// counters zeroed for the next update and scatters the points.  (As the last-ticket block of launch 1 the scan had to
+// counters zeroed for the next update and scatters the points.  (As the last-ticket block of the count launch the scan had to
 // read the counters past its XCD's L2, one sc1 load after the other: 60 us; built in LDS by one workgroup from scratch,
 // count included: 41 us.)  The order of the points inside a cell is whatever the atomics made it: no result depends on
 // it (radius tests look at every point of a cell).
@@ -226,7 +226,7 @@ __device__ __forceinline__ void fuse_grid_scan_scatter(const PointGrid& g, const
 // [q, q + 1) * 65536 / ng: every workgroup reads ALL points, ranks the ones of its cells by LDS atomics on the packed 16-bit
 // counters (the returned old value is the rank) and counts the points of lower cells -- its base, so no workgroup waits for
 // another -- then scans, copies out and scatters its own share.  (cell, rank) of a lane's <= 16 points stay in registers
-// between the count and the scatter.  No launch 1, no 256 KB of global counters to read back and re-zero; the single
+// between the count and the scatter.  No count launch, no 256 KB of global counters to read back and re-zero; the single
 // workgroup's 20 us (the launch's critical path: the slot blocks next to it take 9) divide by ng up to the count pass.
 __device__ __forceinline__ void fuse_grid_build_lds(const PointGrid& g, const float4* __restrict__ pts, uint32_t* __restrict__ parent,
                                                     uint32_t* cnt2 /* [33 * 1024] */, uint32_t* wsum, const uint32_t part, const uint32_t ng) {
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s,
       if (mk_clear_wave<false>(k, s, prev, cnt, slot, lane)) {
         // the generator points of the removed marking, for this update's removePCPtr (launches 4 / 5): into the band of
         // the row of ground cells they fall in, or onto the list of points to be walked one by one.  (Copied now: the
-        // commit of launch 6 may hand the slot to a new cluster.)
+        // commit launch may hand the slot to a new cluster.)
         const uint32_t ofs = s.pts_ofs[slot], n = s.pts_n[slot];
         const float r = (float)k.inflation + 1e-4f;
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
@@ -1048,7 +1048,7 @@ __device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBu
   }
   MKF_STAMP(7);
   // ---- P7: 0.1 m VoxelGrid of the projected points -> generator points; first / count per cluster.  Every generator
-  //      point also goes into the band of the row of ground cells it falls in (launch 6 reads them node by node): ranks
+  //      point also goes into the band of the row of ground cells it falls in (the commit launch reads them node by node): ranks
   //      inside the partition from LDS counters, then ONE device-scope atomic per band and partition (a returning
   //      atomic per point on the ~40 band counters, from 64 partitions at once, cost this phase 15 us) ----
   uint32_t* band_n = L.hist;                                     // [kBandMax] points of this partition per band
@@ -1073,7 +1073,7 @@ __device__ __forceinline__ void fuse_partition(const MarkParams& k, const FuseBu
     const float cntf = (float)(e - j);
     const float4 gp = make_float4(sx / cntf, sy / cntf, sz / cntf, __int_as_float((int)L.gci[cj]));
     fb.gen[gen_base + L.rk[j]] = gp;
-    if (fb.rg.bands && ball_in_range(ground, fb.rg, gp.x, gp.y, rball)) {     // (launch 6 walks the others point by point)
+    if (fb.rg.bands && ball_in_range(ground, fb.rg, gp.x, gp.y, rball)) {     // (the commit launch walks the others point by point)
       const uint32_t band = (uint32_t)(grid_cy(ground, gp.y) - fb.rg.cy0);
       pf[j] = (uint16_t)band;
       L.mine[j] = (uint16_t)atomicAdd(&band_n[band], 1u);

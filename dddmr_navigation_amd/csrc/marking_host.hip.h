@@ -67,7 +67,7 @@ struct MarkingState {
   uint32_t updates_overlapped = 0;
   uint32_t grid_parts = 4;                 // DDDMR_MKF_GRIDPARTS: workgroups that build the observation grid (1, 2, 4, 8)
   bool unmark_with_groups = true;          // DDDMR_MKF_UNMARK=roots: removePCPtr blocks in the seeds' launch instead of the partitions'
-  bool grid_in_lds = true;                 // DDDMR_MKF_GRID=global: counts by launch 1's global atomics instead
+  bool grid_in_lds = true;                 // DDDMR_MKF_GRID=global: counts by a count launch's global atomics instead
   uint32_t splat_parts = 0;                // DDDMR_MKF_PARTS: blocks that share a row segment's bands in the commit launch (0: estimated)
   uint32_t unmark_parts = 8;               // DDDMR_MKF_UNPARTS (tuning)
   uint32_t fuse_cells = kFuseMaxCells;     // DDDMR_MKF_CELLS: cells of the fused route's observation grid (tuning)
