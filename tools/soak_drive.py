@@ -1,13 +1,15 @@
 """Stability soak of the whole chain a deployment runs every control tick: lidar scan -> set_scan (voxel feed,
 stitcher) -> marking / clearing layer update -> tick, with the robot driving laps in the C2 scene for N steps
 (no oracle: it checks that nothing errors, hangs, leaks or drifts -- alive markings stay bounded, every tick returns a
-command or a clean ALL_TRAJECTORIES_FAIL).  usage: python tools/soak_drive.py [steps=3000]"""
+command or a clean ALL_TRAJECTORIES_FAIL).  usage: python tools/soak_drive.py [steps=3000] [overlapped]
+(overlapped: tick_begin -> marking update -> tick_end, the update on its own stream next to the tick's kernels)"""
 import math, sys, time
 import numpy as np
 from dddmr_navigation_amd import _capi as K, configs, marking, scenes
 from dddmr_navigation_amd.local_planner import LocalPlanner
 
 n_steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+overlapped = len(sys.argv) > 2 and sys.argv[2] == "overlapped"
 sc = scenes.bench_scene("C2")
 th = configs.omni_simple_shipped(linear_x_sample=8.0, linear_y_sample=8.0, angular_z_sample=8.0)
 walls = sc.cloud[(np.abs(np.abs(sc.cloud[:, 1]) - 9.9) < 0.05)]
@@ -27,10 +29,17 @@ with LocalPlanner([th], max_points=1 << 16) as lp:
         cloud = sc.cloud if (k // 40) % 3 else sc.cloud[np.hypot(sc.cloud[:, 0] - x - 1.5 * math.cos(yaw), sc.cloud[:, 1] - y - 1.5 * math.sin(yaw)) > 1.0]
         scan = scenes.lidar_scan(cloud, sensor_xyz=(x, y, 0.5), seed=int(rng.integers(1 << 20)))
         lp.set_scan(scan, T_BS, t_gb, 5.0, 2.0)
+        tick_in = scenes.tick_input(pose=t_gb, twist=(0.4, 0.0, 0.1 * math.sin(0.05 * k)))
         t1 = time.perf_counter()
-        st = layer.update(T_BS, t_gb)
-        t2 = time.perf_counter()
-        res = lp.tick(th.name.decode(), scenes.tick_input(pose=t_gb, twist=(0.4, 0.0, 0.1 * math.sin(0.05 * k))))
+        if overlapped:
+            lp.tick_begin(th.name.decode(), tick_in)
+            st = layer.update(T_BS, t_gb)
+            t2 = time.perf_counter()
+            res = lp.tick_end()
+        else:
+            st = layer.update(T_BS, t_gb)
+            t2 = time.perf_counter()
+            res = lp.tick(th.name.decode(), tick_in)
         t3 = time.perf_counter()
         assert res.planner_state in (K.TRAJECTORY_FOUND, K.ALL_TRAJECTORIES_FAIL), res.planner_state
         assert res.best_index >= 0 or res.planner_state == K.ALL_TRAJECTORIES_FAIL
