@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed ticks (default 1000; 400 for C3/C4 on one GPU)")
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C4", "C5", "C5M", "shipped"],
+    ap.add_argument("--workload", default=None, choices=["C2", "C3", "C3P", "C4", "C5", "C5M", "shipped"],
                     help="default: C3 on one GPU, C4 (strong scaling) on several; shipped = only the tick latencies of the "
                          "reference's shipped configurations (55 / 275 / 2 trajectories)")
     ap.add_argument("--inputs", default="static", choices=["static", "moving"],
@@ -237,7 +237,7 @@ def main():
     if base in ("C3", "C4") and world > 1:
         scaling = "strong"
     if args.steps is None:
-        args.steps = 400 if (base in ("C3", "C4") and world == 1) else 1000
+        args.steps = 400 if (base in ("C3", "C3P", "C4") and world == 1) else 1000
     name = theory.name.decode()
     b = configs.BENCH[base]
     n_steps_traj = b["steps"]
@@ -628,7 +628,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and scans is None:
             # the oracle ("port"), ONE core like the reference's loops A and B
             # (local_planner.cpp:549-557, 456-469); median tick of a bounded sample
-            for _ in range(1 if base in ("C3", "C4") else 3):
+            for _ in range(1 if base in ("C3", "C3P", "C4") else 3):
                 oracle.tick(theory, sc.cloud, sc.plan, sc.tick, n_threads=1)
             ticks, kd, gen, scr, t_cpu = [], [], [], [], 0.0
             while (t_cpu < args.cpu_seconds and len(ticks) < 20) or len(ticks) < 3:

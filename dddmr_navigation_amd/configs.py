@@ -153,6 +153,7 @@ BENCH = {
     "C3": dict(kind=K.THEORY_OMNI_SIMPLE, nx=32, ny=16, nth=32, steps=80, sim_time=4.0, points=500_000, seed=3),
     "C4": dict(kind=K.THEORY_OMNI_SIMPLE, nx=64, ny=16, nth=64, steps=50, sim_time=2.5, points=100_000, seed=4),
 }
+BENCH["C3P"] = BENCH["C3"]      # "config 3 also a 10 deg pitch variant" (same theory and cloud, pitched robot pose)
 
 
 def bench_theory(cfg: str) -> K.TheoryConfig:

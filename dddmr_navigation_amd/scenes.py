@@ -233,12 +233,15 @@ def cloud_c3(seed: int = 3, n_points: int = 500_000, layout: str = DEFAULT_LAYOU
 
 
 def bench_scene(cfg: str, layout: str = DEFAULT_LAYOUT) -> Scene:
-    """Scene for BASELINE.json config C1..C4 (C4 = C2's cloud, 65536 samples)."""
+    """Scene for BASELINE.json config C1..C4 (C4 = C2's cloud, 65536 samples; C3P = C3 with the robot pitched 10 degrees)."""
     b = configs.BENCH[cfg]
     if cfg == "C1":
         cloud = cloud_c1(b["seed"], b["points"])
-    elif cfg == "C3":
+    elif cfg in ("C3", "C3P"):
         cloud = cloud_c3(b["seed"], b["points"], layout)
+        if cfg == "C3P":        # the robot on a 10 degree ramp: cuboids tilted out of the grid's axes, poses climbing in z
+            return Scene(cfg, configs.bench_theory(cfg), cloud, s_curve_plan(),
+                         tick_input(pose=(0.0, 0.0, 0.0) + tuple(quat_from_rpy(0.0, math.radians(10.0), 0.0))))
     else:
         cloud = cloud_c2(configs.BENCH["C2"]["seed"] if layout != "r01" else b["seed"], b["points"], layout)
     return Scene(cfg, configs.bench_theory(cfg), cloud, s_curve_plan(), tick_input())

@@ -44,6 +44,7 @@ def main():
     dump("F6_C1", scenes.bench_scene("C1"))
     dump("F7_C2", scenes.bench_scene("C2"))
     dump("F8_C3", scenes.bench_scene("C3"))
+    dump("F9_C3_pitch10", scenes.bench_scene("C3P"))
 
 
 if __name__ == "__main__":

@@ -1,7 +1,7 @@
 """CPU tests of the oracle: known answers derivable by hand from the reference
 source, independent cross-checks of its neighbour search, critic
 unit cases (F2), tie-break (F3), 3-D pose (F4), theory counts (F5) and the
-frozen golden vectors (F1, F6-F8)."""
+frozen golden vectors (F1, F6-F9)."""
 import math
 import os
 
@@ -298,6 +298,21 @@ def test_golden_c3_subrange():
     assert int(g["summary"][1]) == 11536 and o.result.best_index == 11536
     # about a quarter of the C3 trajectories collide (round 1's scene: 86 %)
     assert 0.2 <= float((g["costs"] == -1.0).mean()) <= 0.3
+
+
+def test_golden_c3_pitched_subrange():
+    """SURVEY 8d's pitch variant of config 3 (robot on a 10 degree ramp: F9): a slice of the frozen vector re-scored, and
+    the pitch must show -- the poses climb, so costs differ from the level fixture's on the same samples."""
+    g = np.load(os.path.join(GOLD, "F9_C3_pitch10.npz"))
+    lvl = np.load(os.path.join(GOLD, "F8_C3.npz"))
+    sc = scenes.bench_scene("C3P")
+    assert abs(sc.tick.robot_pose[4] - np.sin(np.radians(5.0))) < 1e-12          # qy of a 10 degree pitch
+    b, e = 11400, 11656
+    o = oracle.tick(sc.theory, sc.cloud, sc.plan, sc.tick, begin=b, end=e, n_threads=4)
+    np.testing.assert_array_equal(o.costs, g["costs"][b:e])
+    np.testing.assert_array_equal(o.steps, g["steps"][b:e])
+    np.testing.assert_array_equal(g["steps"], lvl["steps"])                      # same samples, same step counts
+    assert (g["costs"] != lvl["costs"]).mean() > 0.5
 
 
 def test_feed_oracle_voxel_centroids():

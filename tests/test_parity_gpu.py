@@ -72,6 +72,7 @@ GOLDEN = {
     "F6_C1": lambda: scenes.bench_scene("C1"),
     "F7_C2": lambda: scenes.bench_scene("C2"),
     "F8_C3": lambda: scenes.bench_scene("C3"),
+    "F9_C3_pitch10": lambda: scenes.bench_scene("C3P"),     # config 3 with the robot pitched 10 degrees
 }
 
 
