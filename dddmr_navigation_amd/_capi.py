@@ -206,6 +206,7 @@ EXPORTED_SYMBOLS = (
     "dddmr_rollout_marking_update",
     "dddmr_rollout_marking_reset",
     "dddmr_rollout_marking_get_voxels",
+    "dddmr_rollout_marking_get_points",
     "dddmr_rollout_marking_get_dgraph",
     "dddmr_rollout_marking_get_lethal",
     "dddmr_rollout_marking_route_counts",
@@ -308,6 +309,8 @@ def load_library() -> C.CDLL:
     lib.dddmr_rollout_marking_reset.restype = C.c_int
     lib.dddmr_rollout_marking_get_voxels.argtypes = [ctx_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.dddmr_rollout_marking_get_voxels.restype = C.c_int
+    lib.dddmr_rollout_marking_get_points.argtypes = [ctx_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.dddmr_rollout_marking_get_points.restype = C.c_int
     lib.dddmr_rollout_marking_get_dgraph.argtypes = [ctx_p, C.c_void_p, C.c_size_t]
     lib.dddmr_rollout_marking_get_dgraph.restype = C.c_int
     lib.dddmr_rollout_marking_get_lethal.argtypes = [ctx_p, C.c_void_p, C.c_size_t]

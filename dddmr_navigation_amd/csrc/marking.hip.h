@@ -484,24 +484,30 @@ __global__ __launch_bounds__(64) void k_mk_cluster_stage1(MarkParams k, MarkCoun
 }
 
 // VoxelGrid keys.  A PCL voxel is floor(p * inverse_leaf) per axis (the grid's min_b only shifts the indices), and the
-// output order inside one cloud is x fastest, then y, then z: key = cluster | z | y | x, 14 bits per axis around `org`.
-__device__ __forceinline__ unsigned long long vg_key(uint32_t ci, float x, float y, float z, float inv, int ox, int oy, int oz) {
+// output order inside one cloud is x fastest, then y, then z: key = cluster | z | y | x, 16 + 16 bits for x and y and 10
+// for z around `org` = the window's centre - half the range: +-3.2 km in x / y and +-51 m in z at 0.1 m.  A point of a
+// live cluster beyond that cannot be keyed: capacity flag 4, the update answers DDDMR_ERR_CAPACITY instead of dropping
+// the point.
+constexpr int kVgHalfXY = 32768, kVgHalfZ = 512;
+__device__ __forceinline__ unsigned long long vg_key(uint32_t ci, float x, float y, float z, float inv, int ox, int oy, int oz,
+                                                     MarkCounters* __restrict__ cnt) {
   const int ix = (int)floorf(x * inv) - ox, iy = (int)floorf(y * inv) - oy, iz = (int)floorf(z * inv) - oz;
-  if ((unsigned)ix >= 16384u || (unsigned)iy >= 16384u || (unsigned)iz >= 16384u) return ~0ull;
-  return ((unsigned long long)ci << 42) | ((unsigned long long)iz << 28) | ((unsigned long long)iy << 14) | (unsigned long long)ix;
+  if ((unsigned)ix >= 65536u || (unsigned)iy >= 65536u || (unsigned)iz >= 1024u) { atomicOr(&cnt->overflow, 4u); return ~0ull; }
+  return ((unsigned long long)ci << 42) | ((unsigned long long)iz << 32) | ((unsigned long long)iy << 16) | (unsigned long long)ix;
 }
 // 0.2 m VoxelGrid of the clusters that passed stage 1 (:370-374): key per point, in sort-1 order
 __global__ __launch_bounds__(256) void k_mk_ds_keys(MarkParams k, const unsigned long long* __restrict__ keys1,
                                                     const uint32_t* __restrict__ cid_incl, ClusterArrays c,
                                                     const float4* __restrict__ pts, int ox, int oy, int oz,
-                                                    unsigned long long* __restrict__ keys2, uint32_t* __restrict__ vals2) {
+                                                    unsigned long long* __restrict__ keys2, uint32_t* __restrict__ vals2,
+                                                    MarkCounters* __restrict__ cnt) {
   const uint32_t m = blockIdx.x * 256 + threadIdx.x;
   if (m >= k.n_obs) return;
   const uint32_t ci = cid_incl[m] - 1;
   unsigned long long key = ~0ull;
   if (c.state[ci]) {
     const float4 p = pts[(uint32_t)(keys1[m] & 0xFFFFFu)];
-    key = vg_key(ci, p.x, p.y, p.z, 1.0f / 0.2f, ox, oy, oz);
+    key = vg_key(ci, p.x, p.y, p.z, 1.0f / 0.2f, ox, oy, oz, cnt);
   }
   keys2[m] = key;
   vals2[m] = m;
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(64) void k_mk_cluster_stage2(MarkParams k, const Ma
 __global__ __launch_bounds__(256) void k_mk_proj_keys(MarkParams k, const uint32_t* __restrict__ n_ds, const float4* __restrict__ ds,
                                                       ClusterArrays c, int ox, int oy, int oz, float4* __restrict__ proj,
                                                       unsigned long long* __restrict__ keys3, uint32_t* __restrict__ vals3,
-                                                      uint32_t n_pad) {
+                                                      uint32_t n_pad, MarkCounters* __restrict__ cnt) {
   const uint32_t g = blockIdx.x * 256 + threadIdx.x;
   if (g >= n_pad) return;
   unsigned long long key = ~0ull;
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(256) void k_mk_proj_keys(MarkParams k, const uint32
       const float dist = (m0 * p.x + m2 * p.z) + (m1 * p.y + k.mc[3] * 1.0f);
       const float qx = p.x - m0 * dist, qy = p.y - m1 * dist, qz = p.z - m2 * dist;
       proj[g] = make_float4(qx, qy, qz, p.w);
-      key = vg_key(ci, qx, qy, qz, 1.0f / 0.1f, ox, oy, oz);
+      key = vg_key(ci, qx, qy, qz, 1.0f / 0.1f, ox, oy, oz, cnt);
     }
   }
   keys3[g] = key;

@@ -1,4 +1,4 @@
-// marking_fused.hip.h -- the marking / clearing update for observations of up to 16384 points in FIVE launches.
+// marking_fused.hip.h -- the marking / clearing update for observations of up to 32768 points in FIVE launches.
 //
 // The general route (marking.hip.h + rocPRIM sorts, any observation size) issues ~60 launches per update, ~30 of them
 // at the 4.5-4.9 us launch floor, plus three mid-update copies: for the observation of a 16-line LiDAR the update is
@@ -38,7 +38,8 @@
 
 namespace dddmr {
 
-constexpr uint32_t kFuseMaxObs = 16384;      // points of an observation the fused route takes
+constexpr uint32_t kFuseMaxObs = 32768;      // points of an observation the fused route takes (a 32-line lidar after the 0.1 m feed)
+constexpr uint32_t kFuseRegObs = 16384;      // ... of which the grid builder keeps (cell, rank) in registers; beyond: parked in global memory
 constexpr uint32_t kFuseMaxCells = 65536;    // cells of the observation grid (16-bit counters, two per LDS word: 132 KB)
 constexpr int kFuseParts = 64;               // partitions of the clusters (by hash of the seed point index)
 constexpr uint32_t kPartCap = 4096;          // points one partition workgroup takes (16 per lane)
@@ -55,7 +56,7 @@ __device__ unsigned long long g_mk_stamps[192];   // [0,64) phase stamps of bloc
 
 
 constexpr uint32_t kBandMax = 128;      // y rows of ground cells the window's range may span (else: point by point)
-constexpr uint32_t kBandCap = 16384;    // points one band takes (more: point by point)
+constexpr uint32_t kBandCap = kFuseMaxObs;   // points one band takes (an update makes at most one generator point per observation point)
 
 struct SplatRange {
   int cx0, cx1, cy0, cy1;     // ground-grid cells of the window (+ inflation radius), every z row
@@ -95,6 +96,7 @@ struct FuseBufs {
   unsigned long long* slot;  // [n] (rank << 32) | cell of a point in the observation grid
   MarkCounters* host_out;  // host-mapped copy of the update's counters
   uint32_t grid_in_lds;    // the observation grid is built by the grid launch's first workgroups alone (no count launch)
+  uint32_t* hi_rank;       // [8][kFuseMaxObs - kFuseRegObs] (cell, rank) of the points past kFuseRegObs, per grid workgroup
 };
 
 __device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) {
@@ -228,8 +230,12 @@ __device__ __forceinline__ void fuse_grid_scan_scatter(const PointGrid& g, const
 // another -- then scans, copies out and scatters its own share.  (cell, rank) of a lane's <= 16 points stay in registers
 // between the count and the scatter.  No count launch, no 256 KB of global counters to read back and re-zero; the single
 // workgroup's 20 us (the launch's critical path: the slot blocks next to it take 9) divide by ng up to the count pass.
+// kBig (observations of more than kFuseRegObs points): the points past kFuseRegObs go through the same count in batches of
+// four, their (cell, rank) words parked in hi_rank -- a slice per workgroup, so nobody reads what another wrote.
+template <bool kBig>
 __device__ __forceinline__ void fuse_grid_build_lds(const PointGrid& g, const float4* __restrict__ pts, uint32_t* __restrict__ parent,
-                                                    uint32_t* cnt2 /* [33 * 1024] */, uint32_t* wsum, const uint32_t part, const uint32_t ng) {
+                                                    uint32_t* cnt2 /* [33 * 1024] */, uint32_t* wsum, const uint32_t part, const uint32_t ng,
+                                                    uint32_t* __restrict__ hi_rank) {
   const int tid = threadIdx.x;
   const uint32_t n = g.n, cells = (uint32_t)(g.nx * g.ny * g.nz);
   const uint32_t wpt = 32u / ng;                               // counter words (two cells each) per lane
@@ -271,6 +277,38 @@ __device__ __forceinline__ void fuse_grid_build_lds(const PointGrid& g, const fl
     const uint32_t lc = __float_as_uint(pt[s].w);
     pack[s] = lc == ~0u ? ~0u : (lc | (((pack[s] >> ((lc & 1u) * 16u)) & 0xFFFFu) << 16));
   }
+  uint32_t* my_hi = hi_rank + (size_t)part * (kFuseMaxObs - kFuseRegObs);
+  if (kBig) {
+    for (uint32_t i0 = kFuseRegObs; i0 < n; i0 += 4096u) {
+      float4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * 1024u + tid;
+        q[u] = i < n ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      uint32_t oldw[4], lcs[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * 1024u + tid;
+        lcs[u] = ~0u; oldw[u] = 0u;
+        if (i < n) {
+          const uint32_t cell = (uint32_t)((grid_cz(g, q[u].z) * g.ny + grid_cy(g, q[u].y)) * g.nx + grid_cx(g, q[u].x));
+          lower += cell < c_lo ? 1u : 0u;
+          if (cell >= c_lo && cell < c_hi) {
+            const uint32_t lc = cell - c_lo, wi = lc >> 1;
+            oldw[u] = atomicAdd(&cnt2[wi + (wi >> lw)], 1u << ((lc & 1u) * 16u));
+            lcs[u] = lc;
+          }
+          if (part == 0) parent[i] = i;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * 1024u + tid;
+        if (i < n) my_hi[i - kFuseRegObs] = lcs[u] == ~0u ? ~0u : (lcs[u] | (((oldw[u] >> ((lcs[u] & 1u) * 16u)) & 0xFFFFu) << 16));
+      }
+    }
+  }
   uint32_t base;
   (void)block_excl_scan<16>(lower, wsum, &base);               // (ends with a barrier: the counts are complete too)
   MKF_STAMP(33);
@@ -284,7 +322,7 @@ __device__ __forceinline__ void fuse_grid_build_lds(const PointGrid& g, const fl
   for (uint32_t j = 0; j < wpt; ++j) {
     const uint32_t v = cnt2[tid * (wpt + 1u) + j];
     const uint32_t a = v & 0xFFFFu, b = v >> 16;
-    cnt2[tid * (wpt + 1u) + j] = run | ((run + a) << 16);      // (starts <= 16384 fit 16 bits)
+    cnt2[tid * (wpt + 1u) + j] = run | ((run + a) << 16);      // (starts <= kFuseMaxObs fit 16 bits)
     run += a + b;
   }
   __syncthreads();
@@ -305,6 +343,27 @@ __device__ __forceinline__ void fuse_grid_build_lds(const PointGrid& g, const fl
       g.sorted[st + (pack[s] >> 16)] = make_float4(pt[s].x, pt[s].y, pt[s].z, __int_as_float((int)i));
     }
   }
+  if (kBig) {
+    for (uint32_t i0 = kFuseRegObs; i0 < n; i0 += 4096u) {
+      float4 q[4];
+      uint32_t wd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * 1024u + tid;
+        wd[u] = i < n ? my_hi[i - kFuseRegObs] : ~0u;          // (this lane's own stores)
+        q[u] = i < n ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + (uint32_t)u * 1024u + tid;
+        if (wd[u] != ~0u) {
+          const uint32_t lc = wd[u] & 0xFFFFu, wi = lc >> 1;
+          const uint32_t st = (cnt2[wi + (wi >> lw)] >> ((lc & 1u) * 16u)) & 0xFFFFu;
+          g.sorted[st + (wd[u] >> 16)] = make_float4(q[u].x, q[u].y, q[u].z, __int_as_float((int)i));
+        }
+      }
+    }
+  }
   MKF_STAMP(35);
 }
 
@@ -312,12 +371,13 @@ __device__ __forceinline__ void fuse_grid_build_lds(const PointGrid& g, const fl
 __global__ __launch_bounds__(256) void k_mkf_count(PointGrid obs, FuseBufs fb) { fuse_grid_count(obs, fb.pts, fb.parent, fb.cell_count, fb.slot); }
 
 // grid launch: first blocks: the observation grid  |  the others: every slot of the store
+template <bool kBig>
 __global__ __launch_bounds__(1024) void k_mkf_grid_fov(MarkParams k, MarkStore s, PointGrid obs, FuseBufs fb, MarkCounters* __restrict__ cnt,
                                                        uint32_t nb_grid) {
   __shared__ uint32_t cnt2[33 * 1024];
   __shared__ uint32_t wsum[16];
   if (blockIdx.x < nb_grid) {
-    if (fb.grid_in_lds) fuse_grid_build_lds(obs, fb.pts, fb.parent, cnt2, wsum, blockIdx.x, nb_grid);
+    if (kBig || fb.grid_in_lds) fuse_grid_build_lds<kBig>(obs, fb.pts, fb.parent, cnt2, wsum, blockIdx.x, nb_grid, fb.hi_rank);
     else fuse_grid_scan_scatter(obs, fb.pts, fb.cell_count, fb.slot, cnt2, wsum);
     return;
   }

@@ -52,6 +52,7 @@ struct MarkingState {
   float4* unmark_pts = nullptr;            // [pool_cap]
   float4* band_pts = nullptr;              // [2][kBandMax * kBandCap]: generator points of this update / of removed markings, by row of ground cells
   uint32_t* band_cnt = nullptr;            // [2][kBandMax], all zero between updates
+  uint32_t* hi_rank = nullptr;             // [8][kFuseMaxObs - kFuseRegObs] grid builder scratch for observations past kFuseRegObs points
   uint32_t* clear_list = nullptr;          // [table]
   uint32_t* cell_count = nullptr;          // [kFuseMaxCells], all zero between updates
   bool alive_list_stale = false;           // the fused route keeps no alive list: the general route rebuilds it first
@@ -98,7 +99,7 @@ void marking_free(MarkingState* m) {
                m->gslot, m->parent, m->keys_a, m->keys_b, m->keys1, m->vals_a, m->vals_b, m->flags, m->incl, m->cid_incl, m->ds,
                m->proj, m->gen, m->ds_first, m->pool_ofs, m->compact_sizes, m->compact_ofs, m->cl.start, m->cl.size, m->cl.centroid,
                m->cl.state, m->cl.ds_count, m->cl.gen_first, m->cl.gen_count, m->cl.slot, m->cl.vkey, m->counters, m->n_groups,
-               m->temp, m->unmark_pts, m->ticket, m->clear_list, m->cell_count, m->band_pts, m->band_cnt};
+               m->temp, m->unmark_pts, m->ticket, m->clear_list, m->cell_count, m->band_pts, m->band_cnt, m->hi_rank};
   for (void* q : p)
     if (q) (void)hipFree(q);
   if (m->host_out) (void)hipHostFree(m->host_out);
@@ -386,6 +387,7 @@ int dddmr_rollout_marking_create(dddmr_rollout_ctx* ctx, const dddmr_marking_con
     HIPCHK(ctx, hipMalloc(&m->unmark_pts, (size_t)m->pool_cap * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&m->band_pts, (size_t)2 * kBandMax * kBandCap * sizeof(float4)));
     HIPCHK(ctx, hipMalloc(&m->band_cnt, (size_t)2 * kBandMax * sizeof(uint32_t)));
+    HIPCHK(ctx, hipMalloc(&m->hi_rank, (size_t)8 * (kFuseMaxObs - kFuseRegObs) * sizeof(uint32_t)));
     HIPCHK(ctx, hipMemset(m->band_cnt, 0, (size_t)2 * kBandMax * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&m->clear_list, (size_t)table * sizeof(uint32_t)));
     HIPCHK(ctx, hipMalloc(&m->cell_count, (size_t)kFuseMaxCells * sizeof(uint32_t)));
@@ -533,8 +535,11 @@ int mark_general(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   MK_LAUNCH(m, k_mk_cluster_starts, pb, dim3(256), 0, st, n_obs, m->flags, m->cid_incl, m->cl, m->counters);
   MK_LAUNCH(m, k_mk_cluster_stage1, cb, dim3(64), 0, st, k, m->counters, m->cl, m->keys1, pts, m->ground.g);
   // 0.2 m VoxelGrid of every surviving cluster: stable sort by (cluster, voxel), one lane per voxel
-  const int ox2 = (int)std::floor(lo[0] / 0.2f) - 16, oy2 = (int)std::floor(lo[1] / 0.2f) - 16, oz2 = (int)std::floor(lo[2] / 0.2f) - 16;
-  MK_LAUNCH(m, k_mk_ds_keys, pb, dim3(256), 0, st, k, m->keys1, m->cid_incl, m->cl, pts, ox2, oy2, oz2, m->keys_a, m->vals_a);
+  // (voxel indices are keyed relative to the window's centre - half the key range: an observation handed over uncropped may reach far
+  // beyond the window -- a margin of 16 voxels around the crop box used to drop such points without a word)
+  const float mid[3] = {0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2])};
+  const int ox2 = (int)std::floor(mid[0] / 0.2f) - kVgHalfXY, oy2 = (int)std::floor(mid[1] / 0.2f) - kVgHalfXY, oz2 = (int)std::floor(mid[2] / 0.2f) - kVgHalfZ;
+  MK_LAUNCH(m, k_mk_ds_keys, pb, dim3(256), 0, st, k, m->keys1, m->cid_incl, m->cl, pts, ox2, oy2, oz2, m->keys_a, m->vals_a, m->counters);
   tb = m->temp_bytes;
   HIPCHK(ctx, rocprim::radix_sort_pairs(m->temp, tb, m->keys_a, m->keys_b, m->vals_a, m->vals_b, (size_t)n_obs, 0, 62, st));
   MK_LAUNCH(m, k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys_b, 0, m->flags);
@@ -545,8 +550,8 @@ int mark_general(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
             m->cl.ds_count, m->ds_first, m->n_groups);
   MK_LAUNCH(m, k_mk_cluster_stage2, cb, dim3(64), 0, st, k, m->counters, m->cl, m->map.g, m->n_map);
   // projection on the base plane + 0.1 m VoxelGrid of the accepted clusters -> generator points
-  const int ox3 = (int)std::floor(lo[0] / 0.1f) - 64, oy3 = (int)std::floor(lo[1] / 0.1f) - 64, oz3 = (int)std::floor(lo[2] / 0.1f) - 64;
-  MK_LAUNCH(m, k_mk_proj_keys, pb, dim3(256), 0, st, k, m->n_groups, m->ds, m->cl, ox3, oy3, oz3, m->proj, m->keys_a, m->vals_a, n_obs);
+  const int ox3 = (int)std::floor(mid[0] / 0.1f) - kVgHalfXY, oy3 = (int)std::floor(mid[1] / 0.1f) - kVgHalfXY, oz3 = (int)std::floor(mid[2] / 0.1f) - kVgHalfZ;
+  MK_LAUNCH(m, k_mk_proj_keys, pb, dim3(256), 0, st, k, m->n_groups, m->ds, m->cl, ox3, oy3, oz3, m->proj, m->keys_a, m->vals_a, n_obs, m->counters);
   tb = m->temp_bytes;
   HIPCHK(ctx, rocprim::radix_sort_pairs(m->temp, tb, m->keys_a, m->keys_b, m->vals_a, m->vals_b, (size_t)n_obs, 0, 62, st));
   MK_LAUNCH(m, k_mk_flags, pb, dim3(256), 0, st, n_obs, m->keys_b, 0, m->flags);
@@ -648,7 +653,7 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
   }
   FuseBufs fb{obs, m->parent, m->ds, m->gen, m->clear_list, m->unmark_pts,
               BandList{m->band_pts, m->band_cnt}, BandList{m->band_pts + (size_t)kBandMax * kBandCap, m->band_cnt + kBandMax}, rg,
-              m->ticket, m->cell_count, m->keys_a, m->host_out_dev, m->grid_in_lds ? 1u : 0u};
+              m->ticket, m->cell_count, m->keys_a, m->host_out_dev, m->grid_in_lds ? 1u : 0u, m->hi_rank};
   // Blocks that share one row segment's bands in the commit launch: a block takes every n_part-th 256-point chunk of the
   // 2 delta + 1 bands in reach, so more blocks than chunks only add blocks that read the band counts and leave (measured at
   // C5M, ~110 points per band, 9 bands in reach: n_part 48 / 24 / 16 / 12 / 8 -> mark phase 80 / 68 / 68 / 66 / 67 us).
@@ -665,11 +670,13 @@ int update_fused(dddmr_rollout_ctx* ctx, MarkingState* m, const UpdateFrame& f, 
                  n_obs, m->n_alive_host, rg.rows, rg.segs, rg.bands, rg.delta, n_part);
   const uint32_t nb_band = rg.bands ? rg.rows * seg_groups * n_part : 0u;
   // (DDDMR_MKF_GRID=global only) cell counts of the observation grid
-  if (mark && !m->grid_in_lds) MK_LAUNCH(m, k_mkf_count, dim3((n_obs + 255) / 256), dim3(256), 0, st, gb.g, fb);
+  const bool big = n_obs > kFuseRegObs;          // (the count launch's form of the grid only takes kFuseRegObs points)
+  if (mark && !m->grid_in_lds && !big) MK_LAUNCH(m, k_mkf_count, dim3((n_obs + 255) / 256), dim3(256), 0, st, gb.g, fb);
   // grid launch: the observation grid (built in LDS by the first grid_parts workgroups) | every store slot: window + FOV test -> ray-test list
   {
-    const uint32_t nb_grid = mark ? (m->grid_in_lds ? m->grid_parts : 1u) : 0u;
-    MK_LAUNCH(m, k_mkf_grid_fov, dim3(nb_grid + (m->table + 1023) / 1024), dim3(1024), 0, st, k, s, gb.g, fb, m->counters, nb_grid);
+    const uint32_t nb_grid = mark ? ((m->grid_in_lds || big) ? m->grid_parts : 1u) : 0u;
+    if (big) MK_LAUNCH(m, k_mkf_grid_fov<true>, dim3(nb_grid + (m->table + 1023) / 1024), dim3(1024), 0, st, k, s, gb.g, fb, m->counters, nb_grid);
+    else MK_LAUNCH(m, k_mkf_grid_fov<false>, dim3(nb_grid + (m->table + 1023) / 1024), dim3(1024), 0, st, k, s, gb.g, fb, m->counters, nb_grid);
   }
 #ifdef DDDMR_PHASE_STAMPS
   if (const char* e = std::getenv("DDDMR_MKF_EXP")) { const int v = (std::atoi(e) & 128) ? 1 : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(dddmr::g_mk_exp_noprobe), &v, sizeof(v)); }
@@ -874,7 +881,7 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
     stats->mark_ms = m->last_mark_ms;
   }
   if (out.overflow)
-    return fail(ctx, DDDMR_ERR_CAPACITY, "marking_update: capacity flag %u (1: max_markings, 2: max_cluster_points)", out.overflow);
+    return fail(ctx, DDDMR_ERR_CAPACITY, "marking_update: capacity flag %u (1: max_markings, 2: max_cluster_points, 4: a cluster more than 3.2 km (51 m in z) from the window)", out.overflow);
   return DDDMR_OK;
 }
 
@@ -927,6 +934,42 @@ int dddmr_rollout_marking_get_voxels(dddmr_rollout_ctx* ctx, int32_t* xyz_out, s
     ++cnt;
   }
   *n = cnt;
+  return DDDMR_OK;
+}
+
+// The generator points of every alive marking (the cluster projected on the robot's ground plane, 0.1 m VoxelGrid): what
+// Marking::computeMinDistanceFromObstacle2GroundNodes searches the ground with (cluster_marking.cpp:54-64).  Debug /
+// visualisation (the reference publishes its markings as a cloud); order: by store slot.
+int dddmr_rollout_marking_get_points(dddmr_rollout_ctx* ctx, float* xyz_out, int32_t* voxel_out, size_t capacity, size_t* n) {
+  if (!ctx || !n) return DDDMR_ERR_BAD_ARG;
+  std::lock_guard<std::mutex> tk(ctx->tick_mu);
+  MarkingState* m = ctx->marking;
+  if (!m) return fail(ctx, DDDMR_ERR_STATE, "marking_get_points before marking_create");
+  HIPCHK(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> alive(m->table), ofs(m->table), cnt(m->table);
+  std::vector<unsigned long long> keys(m->table);
+  HIPCHK(ctx, hipMemcpy(keys.data(), m->store.keys, keys.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(alive.data(), m->store.alive, alive.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(ofs.data(), m->store.pts_ofs, ofs.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  HIPCHK(ctx, hipMemcpy(cnt.data(), m->store.pts_n, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  size_t total = 0;
+  for (size_t i = 0; i < alive.size(); ++i)
+    if (alive[i]) total += cnt[i];
+  *n = total;
+  if (!xyz_out) return DDDMR_OK;
+  if (total > capacity) return fail(ctx, DDDMR_ERR_CAPACITY, "marking_get_points: capacity %zu < %zu", capacity, total);
+  std::vector<float4> pool(m->pool_used_host);
+  if (!pool.empty()) HIPCHK(ctx, hipMemcpy(pool.data(), m->store.pool, pool.size() * sizeof(float4), hipMemcpyDeviceToHost));
+  size_t at = 0;
+  for (size_t i = 0; i < alive.size(); ++i) {
+    if (!alive[i]) continue;
+    for (uint32_t j = 0; j < cnt[i]; ++j, ++at) {
+      if ((size_t)ofs[i] + j >= pool.size()) return fail(ctx, DDDMR_ERR_STATE, "marking_get_points: slot %zu points past the pool", i);
+      const float4 p = pool[(size_t)ofs[i] + j];
+      xyz_out[3 * at] = p.x; xyz_out[3 * at + 1] = p.y; xyz_out[3 * at + 2] = p.z;
+      if (voxel_out) voxel_unkey(keys[i], &voxel_out[3 * at], &voxel_out[3 * at + 1], &voxel_out[3 * at + 2]);
+    }
+  }
   return DDDMR_OK;
 }
 

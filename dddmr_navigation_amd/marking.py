@@ -68,6 +68,17 @@ class MarkingLayer:
         self._lp._check(self._lp._lib.dddmr_rollout_marking_route_counts(self._lp._ctx, C.byref(a), C.byref(b), C.byref(n)))
         return {"fused": int(a.value), "general": int(b.value), "launches_last_update": int(n.value)}
 
+    def points(self, with_voxels: bool = False):
+        """Generator points of the alive markings (projected on the ground plane, 0.1 m VoxelGrid), [n, 3] float32;
+        with_voxels: also the voxel key of the marking each point belongs to, [n, 3] int32."""
+        n = C.c_size_t(0)
+        self._lp._check(self._lp._lib.dddmr_rollout_marking_get_points(self._lp._ctx, None, None, 0, C.byref(n)))
+        out = np.zeros((max(n.value, 1), 3), dtype=np.float32)
+        vox = np.zeros((max(n.value, 1), 3), dtype=np.int32)
+        self._lp._check(self._lp._lib.dddmr_rollout_marking_get_points(self._lp._ctx, out.ctypes.data_as(C.c_void_p), vox.ctypes.data_as(C.c_void_p),
+                                                                       out.shape[0], C.byref(n)))
+        return (out[: n.value], vox[: n.value]) if with_voxels else out[: n.value]
+
     def voxels(self) -> np.ndarray:
         n = C.c_size_t(0)
         self._lp._check(self._lp._lib.dddmr_rollout_marking_get_voxels(self._lp._ctx, None, 0, C.byref(n)))

@@ -445,6 +445,13 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
                                  const double T_gbl_base[7], dddmr_marking_stats* stats);
 /* resetdGraph: empty store, dGraph back to max_obstacle_distance. */
 int dddmr_rollout_marking_reset(dddmr_rollout_ctx* ctx);
+/* The generator points of every alive marking -- its cluster projected on the robot's ground plane and
+   downsampled at 0.1 m, what computeMinDistanceFromObstacle2GroundNodes (cluster_marking.cpp:54-64)
+   searches the ground nodes with -- as x y z floats, with the voxel key (x y z ints) of the marking each
+   belongs to in voxel_out (may be NULL); call with xyz_out NULL for the count.  Debug / visualisation
+   (the reference publishes its markings as a cloud). */
+int dddmr_rollout_marking_get_points(dddmr_rollout_ctx* ctx, float* xyz_out, int32_t* voxel_out, size_t capacity,
+                                     size_t* n);
 /* Alive markings as voxel keys (x y z ints, xyz_out[n][3]); call with NULL for the count. */
 int dddmr_rollout_marking_get_voxels(dddmr_rollout_ctx* ctx, int32_t* xyz_out, size_t capacity, size_t* n);
 /* dGraph values of ground nodes 0..n_ground (DynamicGraph::initial fills n + 1 entries) and the

@@ -64,6 +64,7 @@ void oracle_marking_reset(oracle_marking* m);
 int oracle_marking_update(oracle_marking* m, const float* obs_gbl_xyz, size_t n, const double T_base_sensor[7],
                           const double T_gbl_base[7], oracle_marking_stats* stats);
 size_t oracle_marking_get_voxels(oracle_marking* m, int32_t* xyz_out, size_t capacity);
+size_t oracle_marking_get_points(oracle_marking* m, float* xyz_out, int32_t* voxel_out, size_t capacity);
 size_t oracle_marking_get_dgraph(oracle_marking* m, double* out, size_t capacity);
 size_t oracle_marking_get_lethal(oracle_marking* m, uint8_t* flags, size_t capacity);
 size_t oracle_marking_get_decisions(oracle_marking* m, int which, int32_t* voxels, float* margins, uint8_t* flags,

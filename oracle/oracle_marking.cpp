@@ -562,6 +562,34 @@ size_t oracle_marking_get_voxels(oracle_marking* M, int32_t* xyz_out, size_t cap
   return n;
 }
 
+// generator points of every alive marking: pm.pc projected + 0.1 m VoxelGrid as min_distance_to_ground_nodes does
+size_t oracle_marking_get_points(oracle_marking* M, float* xyz_out, int32_t* voxel_out, size_t capacity) {
+  size_t n = 0;
+  for (auto& x : M->marking)
+    for (auto& y : x.second)
+      for (auto& z : y.second) {
+        const PerMarking& pm = z.second;
+        if (!pm.has_pc) continue;
+        float mc[4] = {pm.mc[0], pm.mc[1], pm.mc[2], 0.0f};
+        const float nrm = std::sqrt((mc[0] * mc[0] + mc[2] * mc[2]) + (mc[1] * mc[1] + mc[3] * mc[3]));
+        for (float& v : mc) v = v / nrm;
+        const float tmp_mc[4] = {mc[0], mc[1], mc[2], pm.mc[3]};
+        std::vector<F4> proj(pm.pc.size());
+        for (size_t i = 0; i < pm.pc.size(); ++i) {
+          const float p[4] = {pm.pc[i].x, pm.pc[i].y, pm.pc[i].z, 1.0f};
+          const float dist = (tmp_mc[0] * p[0] + tmp_mc[2] * p[2]) + (tmp_mc[1] * p[1] + tmp_mc[3] * p[3]);
+          proj[i] = F4{p[0] - mc[0] * dist, p[1] - mc[1] * dist, p[2] - mc[2] * dist, pm.pc[i].i};
+        }
+        voxel_grid(proj, 0.1f);
+        for (const F4& q : proj) {
+          if (xyz_out && n < capacity) { xyz_out[3 * n] = q.x; xyz_out[3 * n + 1] = q.y; xyz_out[3 * n + 2] = q.z; }
+          if (voxel_out && n < capacity) { voxel_out[3 * n] = x.first; voxel_out[3 * n + 1] = y.first; voxel_out[3 * n + 2] = z.first; }
+          ++n;
+        }
+      }
+  return n;
+}
+
 size_t oracle_marking_get_dgraph(oracle_marking* M, double* out, size_t capacity) {
   const size_t n = std::min(capacity, M->dgraph.size());
   if (out) std::memcpy(out, M->dgraph.data(), n * sizeof(double));

@@ -185,6 +185,8 @@ class MarkingOracle:
         lib.oracle_marking_update.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_double),
                                               C.POINTER(C.c_double), C.POINTER(K.MarkingStats)]
         lib.oracle_marking_update.restype = C.c_int
+        lib.oracle_marking_get_points.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.oracle_marking_get_points.restype = C.c_size_t
         for f in (lib.oracle_marking_get_voxels, lib.oracle_marking_get_dgraph, lib.oracle_marking_get_lethal):
             f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
             f.restype = C.c_size_t
@@ -223,6 +225,14 @@ class MarkingOracle:
         out = np.zeros((max(n, 1), 3), dtype=np.int32)
         self._lib.oracle_marking_get_voxels(self._h, _ptr(out), len(out))
         return out[:n]
+
+    def points(self, with_voxels: bool = False):
+        """generator points of the alive markings (what the dGraph update searches the ground nodes with)"""
+        n = self._lib.oracle_marking_get_points(self._h, None, None, 0)
+        out = np.zeros((max(n, 1), 3), dtype=np.float32)
+        vox = np.zeros((max(n, 1), 3), dtype=np.int32)
+        self._lib.oracle_marking_get_points(self._h, _ptr(out), _ptr(vox), len(out))
+        return (out[:n], vox[:n]) if with_voxels else out[:n]
 
     def dgraph(self) -> np.ndarray:
         out = np.zeros(self.n_ground + 1, dtype=np.float64)

@@ -271,14 +271,20 @@ def test_long_sequence_with_many_compactions():
     assert totals["marked"] > 1000 and totals["cleared"] > 100
 
 
-@pytest.mark.parametrize("n_points", [3000, 4096, 4097, 8192, 8193, 15000, 16384])
-def test_observation_sizes_of_every_fused_instantiation(n_points, route):
-    """The fused route sorts with 4, 8 or 16 elements per lane (observations of up to 4096 / 8192 / 16384 points):
-    clouds handed over with set_cloud at and around those sizes, three updates each with the robot moving."""
+@pytest.mark.parametrize("n_points,tol", [(3000, 0.12), (4096, 0.12), (4097, 0.12), (8192, 0.12), (8193, 0.12), (15000, 0.12), (16384, 0.12),
+                                          (16385, 0.075), (20481, 0.075), (27000, 0.075), (32768, 0.075), (27000, 0.12)])
+def test_observation_sizes_of_every_fused_instantiation(n_points, tol, route):
+    """Clouds handed over with set_cloud at and around the sizes where the fused route changes gear (the grid builder keeps
+    16 points per lane in registers up to 16384 points and parks the rest in global memory up to 32768, the seed scan
+    and the radix sorts change their batch counts at multiples of 4096), three updates each with the robot moving.  The
+    bigger clouds reach 4 m beyond the layer's window on every side (a cloud handed over uncropped; the general route used
+    to drop points more than 3.2 m outside it without a word), and with the wide tolerance their largest cluster (5077
+    points) exceeds a partition workgroup: the fused route must hand the mark phase to the general one."""
     _, cloud, walls, _ = _scene()
     rng = np.random.default_rng(n_points)
-    near = cloud[(np.abs(cloud[:, 0] - 1.0) < 5.0) & (np.abs(cloud[:, 1]) < 5.0) & (cloud[:, 2] > 0.05) & (cloud[:, 2] < 2.0)]
-    cfg = marking.shipped_config(euclidean_cluster_extraction_tolerance=0.12)
+    half = 5.0 if n_points <= 16384 else 9.0
+    near = cloud[(np.abs(cloud[:, 0] - 1.0) < half) & (np.abs(cloud[:, 1]) < half) & (cloud[:, 2] > 0.05) & (cloud[:, 2] < 2.0)]
+    cfg = marking.shipped_config(euclidean_cluster_extraction_tolerance=tol)
     ground = marking.ground_lattice()
     mo = oracle.MarkingOracle(cfg, ground, walls[:, :3])
     sc = scenes.bench_scene("C2")
@@ -297,7 +303,13 @@ def test_observation_sizes_of_every_fused_instantiation(n_points, route):
             assert _vset(layer.voxels()) == _vset(mo.voxels())
             np.testing.assert_array_equal(layer.lethal(), mo.lethal())
             np.testing.assert_array_equal(layer.dgraph(), mo.dgraph())
-        _check_route(layer, 3)
+            gp, gv = layer.points(with_voxels=True)
+            op, ov = mo.points(with_voxels=True)
+            assert sorted(map(tuple, np.concatenate([gv, gp], axis=1).tolist())) == sorted(map(tuple, np.concatenate([ov, op], axis=1).tolist()))
+        if n_points > 16384 and tol > 0.1:
+            assert layer.route_counts()["general"] == 3            # (by choice or by fallback)
+        else:
+            _check_route(layer, 3)
 
 
 def test_observation_too_wide_for_the_fused_sort_keys_falls_back(monkeypatch):
@@ -332,16 +344,17 @@ def test_observation_too_wide_for_the_fused_sort_keys_falls_back(monkeypatch):
 def test_observation_larger_than_the_fused_route_takes_the_general_one(monkeypatch):
     monkeypatch.setenv("DDDMR_MARKING_ROUTE", "auto")
     _, cloud, walls, _ = _scene()
-    near = cloud[(np.abs(cloud[:, 0]) < 6.0) & (np.abs(cloud[:, 1]) < 6.0) & (cloud[:, 2] > 0.05) & (cloud[:, 2] < 2.0)]
-    assert len(near) > 20000
+    near = cloud[(cloud[:, 2] > 0.05) & (cloud[:, 2] < 2.0)]
+    assert len(near) > 2 * 36000
     cfg = marking.shipped_config(perception_window_size=6.0)
     ground = marking.ground_lattice()
     mo = oracle.MarkingOracle(cfg, ground, walls[:, :3])
     sc = scenes.bench_scene("C2")
     with LocalPlanner([sc.theory], max_points=1 << 16) as lp:
         layer = marking.MarkingLayer(lp, cfg, ground, walls[:, :3])
-        for k, nobs in enumerate([20000, 9000, 17000]):
-            obs = np.ascontiguousarray(near[k::2][:nobs], dtype=np.float32)
+        inner = near[(np.abs(near[:, 0]) < 5.0) & (np.abs(near[:, 1]) < 5.0)]
+        for k, nobs in enumerate([36000, 9000, 33000]):
+            obs = np.ascontiguousarray((near if nobs > 32768 else inner)[k::2][:nobs], dtype=np.float32)
             t_gb = (0.2 * k, 0.0, 0.0, 0, 0, 0, 1)
             lp.set_cloud(obs)
             st = layer.update(T_BS, t_gb)
