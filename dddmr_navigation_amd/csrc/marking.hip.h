@@ -52,6 +52,13 @@ struct PointGrid {            // uniform grid over a point set; cell = (cz * ny 
 __device__ __forceinline__ int grid_cx(const PointGrid& g, float x) { return min(max((int)floorf((x - g.ox) * g.inv_xy), 0), g.nx - 1); }
 __device__ __forceinline__ int grid_cy(const PointGrid& g, float y) { return min(max((int)floorf((y - g.oy) * g.inv_xy), 0), g.ny - 1); }
 __device__ __forceinline__ int grid_cz(const PointGrid& g, float z) { return min(max((int)floorf((z - g.oz) * g.inv_z), 0), g.nz - 1); }
+// Cell of q + d (a search ball's edge), the origin subtracted FIRST: q - origin is a small number carried exactly or to
+// ~1e-6 m, whereas q + d rounds to the float grid of q -- 0.24 mm at 4 km, more than the 0.1 mm by which the callers
+// widen their balls, so that a neighbour could fall into a cell outside the range (found with the scene shifted by
+// kilometres: tests/test_marking_gpu.py::test_marking_far_from_the_map_origin).
+__device__ __forceinline__ int grid_cx(const PointGrid& g, float q, float d) { return min(max((int)floorf(((q - g.ox) + d) * g.inv_xy), 0), g.nx - 1); }
+__device__ __forceinline__ int grid_cy(const PointGrid& g, float q, float d) { return min(max((int)floorf(((q - g.oy) + d) * g.inv_xy), 0), g.ny - 1); }
+__device__ __forceinline__ int grid_cz(const PointGrid& g, float q, float d) { return min(max((int)floorf(((q - g.oz) + d) * g.inv_z), 0), g.nz - 1); }
 
 __global__ __launch_bounds__(256) void k_grid_count(PointGrid g, const float4* __restrict__ pts, uint32_t* __restrict__ counts,
                                                     uint2* __restrict__ slot) {
@@ -72,9 +79,9 @@ __global__ __launch_bounds__(256) void k_grid_scatter(PointGrid g, const float4*
 // All points of the cells the ball's bounding box touches (the caller applies FLANN's float distance test).
 template <class F>
 __device__ __forceinline__ void grid_for_each(const PointGrid& g, float qx, float qy, float qz, float r, F&& f) {
-  const int x0 = grid_cx(g, qx - r), x1 = grid_cx(g, qx + r);
-  const int y0 = grid_cy(g, qy - r), y1 = grid_cy(g, qy + r);
-  const int z0 = grid_cz(g, qz - r), z1 = grid_cz(g, qz + r);
+  const int x0 = grid_cx(g, qx, -r), x1 = grid_cx(g, qx, r);
+  const int y0 = grid_cy(g, qy, -r), y1 = grid_cy(g, qy, r);
+  const int z0 = grid_cz(g, qz, -r), z1 = grid_cz(g, qz, r);
   const int nys = y1 - y0 + 1, nrows = nys * (z1 - z0 + 1);
   if (nrows <= 4 && nys <= 2) {
     // The usual case (a ball no wider than a cell: at most 2 x 2 rows of cells): the bounds of all rows and the first point
@@ -115,9 +122,9 @@ __device__ __forceinline__ void grid_for_each(const PointGrid& g, float qx, floa
 // The same walk with the 64 lanes of a wave striding each row's run (one query per wave).
 template <class F>
 __device__ __forceinline__ void grid_for_each_wave(const PointGrid& g, float qx, float qy, float qz, float r, int lane, F&& f) {
-  const int x0 = grid_cx(g, qx - r), x1 = grid_cx(g, qx + r);
-  const int y0 = grid_cy(g, qy - r), y1 = grid_cy(g, qy + r);
-  const int z0 = grid_cz(g, qz - r), z1 = grid_cz(g, qz + r);
+  const int x0 = grid_cx(g, qx, -r), x1 = grid_cx(g, qx, r);
+  const int y0 = grid_cy(g, qy, -r), y1 = grid_cy(g, qy, r);
+  const int z0 = grid_cz(g, qz, -r), z1 = grid_cz(g, qz, r);
   for (int cz = z0; cz <= z1; ++cz)
     for (int cy = y0; cy <= y1; ++cy) {
       const uint32_t b = g.cell_start[(cz * g.ny + cy) * g.nx + x0], e = g.cell_start[(cz * g.ny + cy) * g.nx + x1 + 1];
@@ -154,6 +161,7 @@ struct MarkParams {
   uint32_t n_ground;
   uint32_t seq;                // update sequence number
   uint32_t n_alive_prev;       // entries of MarkStore::alive_list
+  float pad;                   // by how much the ray probes' and the still-observed test's search boxes are widened (1e-4 m)
 };
 
 struct MarkCounters {         // device counters of one update (copied back for dddmr_marking_stats)
@@ -321,7 +329,7 @@ __device__ __forceinline__ bool mk_clear_wave(const MarkParams& k, const MarkSto
 #ifdef DDDMR_PHASE_STAMPS
           if (!g_mk_exp_noprobe)
 #endif
-          hit = grid_radius_count(prev, ax, ay, az, (float)sd + 1e-4f, r2, 1) > 0;
+          hit = grid_radius_count(prev, ax, ay, az, (float)sd + k.pad, r2, 1) > 0;
         }
       }
       const unsigned long long m_end = __ballot(!live || stop);    // first lane at which the reference's loop ends
@@ -338,7 +346,7 @@ __device__ __forceinline__ bool mk_clear_wave(const MarkParams& k, const MarkSto
   int near = 0;
   if (!observation_clear) {
     const float r2 = static_cast<float>(k.res * k.res);
-    near = grid_radius_count(prev, px, py, pz, (float)k.res + 1e-4f, r2, 2);
+    near = grid_radius_count(prev, px, py, pz, (float)k.res + k.pad, r2, 2);
   }
   const long long mkc3 = MKC_NOW();
   MKC_ADD(4, mkc3 - mkc2);

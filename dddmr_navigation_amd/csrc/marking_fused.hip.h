@@ -70,7 +70,7 @@ struct BandList {             // points bucketed by the y row of ground cells th
   uint32_t* cnt;              // [kBandMax], all zero between updates
 };
 __device__ __forceinline__ bool ball_in_range(const PointGrid& g, const SplatRange& rg, float qx, float qy, float r) {
-  return grid_cx(g, qx - r) >= rg.cx0 && grid_cx(g, qx + r) <= rg.cx1 && grid_cy(g, qy - r) >= rg.cy0 && grid_cy(g, qy + r) <= rg.cy1;
+  return grid_cx(g, qx, -r) >= rg.cx0 && grid_cx(g, qx, r) <= rg.cx1 && grid_cy(g, qy, -r) >= rg.cy0 && grid_cy(g, qy, r) <= rg.cy1;
 }
 // true: the point went into its band (the node-by-node pass will see it); false: it has to be walked point by point
 __device__ __forceinline__ bool band_push(const PointGrid& g, const SplatRange& rg, const BandList& b, const float4 p, const float r) {
@@ -472,9 +472,9 @@ __global__ __launch_bounds__(256) void k_mkf_clear_cc(MarkParams k, MarkStore s,
   if (i >= k.n_obs) return;
   const float4 p = fb.pts[i];
   const float r = k.tol + 1e-4f;
-  const int x0 = grid_cx(obs, p.x - r), x1 = grid_cx(obs, p.x + r);
-  const int y0 = grid_cy(obs, p.y - r), y1 = grid_cy(obs, p.y + r);
-  const int z0 = grid_cz(obs, p.z - r), z1 = grid_cz(obs, p.z + r);
+  const int x0 = grid_cx(obs, p.x, -r), x1 = grid_cx(obs, p.x, r);
+  const int y0 = grid_cy(obs, p.y, -r), y1 = grid_cy(obs, p.y, r);
+  const int z0 = grid_cz(obs, p.z, -r), z1 = grid_cz(obs, p.z, r);
   const int nys = y1 - y0 + 1, nrows = nys * (z1 - z0 + 1);
   for (int rr = sub; rr < nrows; rr += 4) {
     const int cz = z0 + rr / nys, cy = y0 + rr % nys;
@@ -507,9 +507,9 @@ __device__ __forceinline__ void fuse_roots(uint32_t n, uint32_t* parent, Cluster
 // ---------------------------------------------------------------------------------------------
 template <class F>
 __device__ __forceinline__ void ground_ball_wave(const PointGrid& g, float qx, float qy, float qz, float r, int lane, F&& f) {
-  const int x0 = grid_cx(g, qx - r), x1 = grid_cx(g, qx + r);
-  const int y0 = grid_cy(g, qy - r), y1 = grid_cy(g, qy + r);
-  const int z0 = grid_cz(g, qz - r), z1 = grid_cz(g, qz + r);
+  const int x0 = grid_cx(g, qx, -r), x1 = grid_cx(g, qx, r);
+  const int y0 = grid_cy(g, qy, -r), y1 = grid_cy(g, qy, r);
+  const int z0 = grid_cz(g, qz, -r), z1 = grid_cz(g, qz, r);
   const int nys = y1 - y0 + 1, nrows = nys * (z1 - z0 + 1);
   for (int r0 = 0; r0 < nrows; r0 += 64) {
     const int rr = r0 + lane;

@@ -843,6 +843,8 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx* ctx, const double T_base_sen
   k.wz1 = (int)((T_gbl_base[2] + c.marking_height) / c.height_resolution);
   k.n_obs = n_obs;
   k.n_prev = m->prev >= 0 ? m->n_prev : 0;
+  k.pad = 1e-4f;
+  if (const char* e = std::getenv("DDDMR_MK_PAD")) k.pad = (float)std::atof(e);      // (diagnosis)
   k.table_mask = m->table - 1;
   k.pool_cap = m->pool_cap;
   k.n_ground = m->n_ground;

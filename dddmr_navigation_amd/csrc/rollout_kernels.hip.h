@@ -1365,11 +1365,15 @@ __global__ __launch_bounds__(kScoreThreads, kScoreThreads >= 512 ? DDDMR_SCORE_W
       // vertices' own bounding box for the min-max critic -- clipped to the 1 m search ball's box, plus 0.1 mm + 1e-5
       // of the extent for the float rounding of the reference's normalised axes (more cells never change a result; a
       // missing one loses a collision).
-      const float ocx = ccx / 8.f, ocy = ccy / 8.f;
-      const float lox = fmaxf(fminf(mnx, ocx - obx), px - 1.0f), hix = fminf(fmaxf(mxx, ocx + obx), px + 1.0f);
-      const float loy = fmaxf(fminf(mny, ocy - oby), py - 1.0f), hiy = fminf(fmaxf(mxy, ocy + oby), py + 1.0f);
-      int cx0 = (int)floorf((lox - k.gmin[0]) * k.inv_cell), cx1 = (int)floorf((hix - k.gmin[0]) * k.inv_cell);
-      int cy0 = (int)floorf((loy - k.gmin[1]) * k.inv_cell), cy1 = (int)floorf((hiy - k.gmin[1]) * k.inv_cell);
+      // (everything relative to the tile's corner BEFORE the extents are added: `centre - extent` in map coordinates
+      // rounds to the float grid of the centre -- 0.24 mm at 4 km, more than the 0.1 mm margin above -- while
+      // `(centre - corner) - extent` is carried to ~1e-6 m, like the cell a point was binned into)
+      const float gx = k.gmin[0], gy = k.gmin[1];
+      const float ocx = ccx / 8.f - gx, ocy = ccy / 8.f - gy, prx = px - gx, pry = py - gy;
+      const float lox = fmaxf(fminf(mnx - gx, ocx - obx), prx - 1.0f), hix = fminf(fmaxf(mxx - gx, ocx + obx), prx + 1.0f);
+      const float loy = fmaxf(fminf(mny - gy, ocy - oby), pry - 1.0f), hiy = fminf(fmaxf(mxy - gy, ocy + oby), pry + 1.0f);
+      int cx0 = (int)floorf(lox * k.inv_cell), cx1 = (int)floorf(hix * k.inv_cell);
+      int cy0 = (int)floorf(loy * k.inv_cell), cy1 = (int)floorf(hiy * k.inv_cell);
       cx0 = max(cx0, 0); cy0 = max(cy0, 0);
       cx1 = min(cx1, k.gnx - 1); cy1 = min(cy1, k.gny - 1);
       if (cx0 > cx1 || cy0 > cy1) { cx0 = 1; cx1 = 0; cy0 = 1; cy1 = 0; }

@@ -409,3 +409,20 @@ def test_update_next_to_a_pending_tick_gives_the_serial_results():
         assert e.value.code == K.ERR_STATE
         assert fields(b.tick_end())[:2] == fields(rb)[:2]
         np.testing.assert_array_equal(la.dgraph(), lb.dgraph())
+
+
+@pytest.mark.parametrize("offset", [(1500.0, -800.0, 30.0), (-4200.5, 3100.25, -12.0)])
+def test_marking_far_from_the_map_origin(offset):
+    """The C2 scene, the ground nodes and the robot shifted by kilometres (voxel keys of tens of thousands, floats that
+    carry 0.1 - 0.5 mm): a ten-scan sequence with a vanishing obstacle, identical to the oracle update by update."""
+    sc, cloud, walls, _ = _scene()
+    off = np.array(offset, dtype=np.float64)
+    sh = lambda a: np.concatenate([(a[:, :3].astype(np.float64) + off).astype(np.float32), a[:, 3:]], axis=1)
+    cloud_s, walls_s = sh(cloud), sh(walls)
+    ground = (marking.ground_lattice().astype(np.float64) + off).astype(np.float32)
+    cfg = marking.shipped_config()
+    poses = lambda k: (off[0] + 0.25 * k, off[1] + 0.05 * k, off[2], 0, 0, math.sin(0.03 * k), math.cos(0.03 * k))
+    gone = np.hypot(cloud_s[:, 0] - (off[0] + 2.0), cloud_s[:, 1] - off[1]) > 1.2
+    scene_of = lambda k, c: cloud_s if k < 5 else cloud_s[gone]
+    totals, final = _run_sequence(cfg, walls_s, poses, scene_of, ground=ground, n_updates=10, fragile_tol=1e-5)
+    assert totals["marked"] > 500

@@ -593,3 +593,21 @@ def test_heading_sincos_is_within_one_ulp_of_long_double():
         ulp = np.spacing(np.abs(ref.astype(np.float64))).astype(np.longdouble)
         err = np.abs(got.astype(np.longdouble) - ref) / ulp
         assert float(err.max()) < 1.0, (float(err.max()), float(ang[int(err.argmax())]))
+
+
+@pytest.mark.parametrize("offset", [(1500.0, -800.0, 30.0), (-4200.5, 3100.25, -12.0)])
+@pytest.mark.parametrize("cfg", ["C1", "C2"])
+def test_robot_far_from_the_map_origin(cfg, offset):
+    """Map coordinates of kilometres (a float carries 0.1 - 0.5 mm there): the whole scene, plan and robot pose shifted.
+    The reference's float box / radius / 1-NN tests then work on big numbers; the device does the same float
+    operations in the same order, so verdicts, costs and the winner still have to be the oracle's."""
+    sc = scenes.bench_scene(cfg)
+    off = np.array(offset, dtype=np.float64)
+    cloud = sc.cloud.copy()
+    cloud[:, :3] = (cloud[:, :3].astype(np.float64) + off).astype(np.float32)
+    plan = sc.plan.copy()
+    plan[:, :3] += off
+    yaw = 0.3
+    pose = tuple(off) + tuple(scenes.quat_from_rpy(0.0, 0.0, 0.0))
+    res, costs, o = against_oracle(sc.theory, cloud, plan, scenes.tick_input(pose=pose))
+    assert (costs == -1.0).any() and (costs >= 0).any() and res.best_index >= 0
