@@ -241,7 +241,18 @@ def test_random_marking_sequences(seed):
         hx, hy, hr = holes[k]
         return cloud[np.hypot(cloud[:, 0] - hx, cloud[:, 1] - hy) > hr]
 
-    totals, final = _run_sequence(cfg, static_map, poses, scene_of, n_updates=n_updates, fragile_tol=1e-5)
+    ground = None
+    if os.environ.get("DDDMR_RANDOM_SHIFT"):
+        # the whole scenario moved by a map-scale offset ("x,y,z" in metres)
+        off = np.array([float(v) for v in os.environ["DDDMR_RANDOM_SHIFT"].split(",")], dtype=np.float64)
+        _, cloud0, _, _ = _scene()
+        sh = lambda a: np.concatenate([(a[:, :3].astype(np.float64) + off).astype(np.float32), a[:, 3:]], axis=1)
+        cloud_s, static_map = sh(cloud0), sh(static_map)
+        ground = (marking.ground_lattice().astype(np.float64) + off).astype(np.float32)
+        poses0, scene0 = poses, scene_of
+        poses = lambda k: tuple(np.array(poses0(k)[:3]) + off) + tuple(poses0(k)[3:])
+        scene_of = lambda k, c: sh(scene0(k, cloud0))
+    totals, final = _run_sequence(cfg, static_map, poses, scene_of, ground=ground, n_updates=n_updates, fragile_tol=1e-5)
     assert totals["clusters"] > 0 or final is None
 
 

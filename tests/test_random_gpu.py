@@ -26,6 +26,10 @@ WILD = os.environ.get("DDDMR_RANDOM_WILD", "0") not in ("", "0")
 SCALE = int(os.environ.get("DDDMR_RANDOM_SCALE", "1"))
 
 
+SHIFT = (np.array([float(v) for v in os.environ["DDDMR_RANDOM_SHIFT"].split(",")], dtype=np.float64)
+         if os.environ.get("DDDMR_RANDOM_SHIFT") else None)
+
+
 def random_case(rng, permute_stack=False, wild=None):
     WILD = globals()["WILD"] if wild is None else wild
     kind = rng.choice(["dd", "omni", "rot"], p=[0.45, 0.4, 0.15])
@@ -127,6 +131,14 @@ def random_case(rng, permute_stack=False, wild=None):
         plan[i, 1] = pos[1] + s * math.sin(yaw0)
         plan[i, 2] = pos[2] + 0.02 * s
         plan[i, 3:7] = scenes.quat_from_rpy(0.0, 0.02, yaw0 + 0.3 * math.sin(s))
+    if SHIFT is not None:
+        # DDDMR_RANDOM_SHIFT="x,y,z": the whole scenario moved by a map-scale offset (a float carries 0.1 - 0.5 mm at
+        # kilometres: the reference's float tests then work on big numbers, and so must the device)
+        cloud = cloud.copy()
+        cloud[:, :3] = (cloud[:, :3].astype(np.float64) + SHIFT).astype(np.float32)
+        plan[:, :3] += SHIFT
+        for a in range(3):
+            tick.robot_pose[a] = float(tick.robot_pose[a]) + float(SHIFT[a])
     return th, cloud, plan, tick
 
 
