@@ -611,3 +611,19 @@ def test_robot_far_from_the_map_origin(cfg, offset):
     pose = tuple(off) + tuple(scenes.quat_from_rpy(0.0, 0.0, 0.0))
     res, costs, o = against_oracle(sc.theory, cloud, plan, scenes.tick_input(pose=pose))
     assert (costs == -1.0).any() and (costs >= 0).any() and res.best_index >= 0
+
+
+def test_non_finite_cloud_points_are_ignored():
+    """Out of contract (the reference's PassThrough filters drop non-finite points before the aggregate is built), but a
+    cloud handed over raw must not derail the tick: NaN / inf records change nothing."""
+    sc = scenes.bench_scene("C1")
+    bad = np.array([[np.nan, 0.0, 0.3, 0], [0.5, np.nan, 0.3, 0], [0.5, 0.0, np.nan, 0], [np.inf, 0.0, 0.3, 0],
+                    [0.5, -np.inf, 0.3, 0], [np.nan, np.nan, np.nan, np.nan]], dtype=np.float32)
+    dirty = np.concatenate([sc.cloud[:2000], bad, sc.cloud[2000:], bad[::-1]])
+    clean = gpu_tick(sc.theory, sc.cloud, sc.plan, sc.tick)
+    got = gpu_tick(sc.theory, dirty, sc.plan, sc.tick)
+    assert (got[0].planner_state, got[0].best_index, got[0].best_cost, got[0].vx, got[0].vy, got[0].wz) == \
+           (clean[0].planner_state, clean[0].best_index, clean[0].best_cost, clean[0].vx, clean[0].vy, clean[0].wz)
+    np.testing.assert_array_equal(got[1], clean[1])
+    np.testing.assert_array_equal(got[2], clean[2])
+    assert got[0].n_points_binned == clean[0].n_points_binned
