@@ -437,3 +437,16 @@ def test_marking_far_from_the_map_origin(offset):
     scene_of = lambda k, c: cloud_s if k < 5 else cloud_s[gone]
     totals, final = _run_sequence(cfg, walls_s, poses, scene_of, ground=ground, n_updates=10, fragile_tol=1e-5)
     assert totals["marked"] > 500
+
+
+def test_window_wider_than_the_band_table():
+    """A 35 m window spans more rows of ground cells than the node-centric dGraph update has bands (128): the fused route
+    then walks every generator point one by one (as the general route always does); five updates with a moving robot,
+    identical to the oracle."""
+    sc, cloud, walls, _ = _scene()
+    cfg = marking.shipped_config(perception_window_size=35.0, inflation_radius=1.2)
+    ground = marking.ground_lattice(half=40.0, spacing=0.5)
+    poses = lambda k: (0.5 * k, -0.1 * k, 0.0, 0, 0, math.sin(0.05 * k), math.cos(0.05 * k))
+    scene_of = lambda k, c: c if k % 2 == 0 else c[np.hypot(c[:, 0] - 3.0, c[:, 1] - 1.0) > 1.5]
+    totals, final = _run_sequence(cfg, walls, poses, scene_of, window=35.0, ground=ground, n_updates=5, fragile_tol=1e-5)
+    assert totals["marked"] > 1000 and totals["cleared"] > 100
