@@ -223,6 +223,10 @@ def test_random_marking_sequences(seed):
         cfg.scan_effective_negative_start, cfg.scan_effective_negative_end = -float(wr.uniform(5.0, 60.0)), -float(wr.uniform(120.0, 180.0))
         cfg.vertical_FOV_top, cfg.vertical_FOV_bottom = float(wr.uniform(5.0, 30.0)), -float(wr.uniform(5.0, 30.0))
         tilt = float(wr.choice([0.04, 0.15, 0.3]))
+        yaw_step = float(wr.choice([0.0, 0.2, 0.9])) if os.environ.get("DDDMR_RANDOM_YAW", "0") not in ("", "0") else 0.0
+        yaw0 = float(wr.uniform(-math.pi, math.pi)) if yaw_step else 0.0
+    else:
+        yaw_step, yaw0 = 0.0, 0.0
     static_map = walls if rng.random() < 0.5 else np.concatenate([walls, corridor])
     n_updates = 8
     xs = np.cumsum(rng.uniform(0.0, 0.4, n_updates))
@@ -233,7 +237,9 @@ def test_random_marking_sequences(seed):
              if rng.random() < 0.5 else None for _ in range(n_updates)]
 
     def poses(k):
-        return (float(xs[k]), float(ys[k]), float(zs[k])) + tuple(scenes.quat_from_rpy(float(rp[k, 0]), float(rp[k, 1]), 0.0))
+        # (DDDMR_RANDOM_YAW with DDDMR_RANDOM_WILD: the robot also turns, from any heading -- the azimuth limits of
+        # isinLidarObservation and the wrap of its shortest-angle at +-pi)
+        return (float(xs[k]), float(ys[k]), float(zs[k])) + tuple(scenes.quat_from_rpy(float(rp[k, 0]), float(rp[k, 1]), yaw0 + yaw_step * k))
 
     def scene_of(k, cloud):
         if holes[k] is None:
