@@ -64,14 +64,22 @@ def _run_sequence(cfg, static_map, poses, scene_of, window=5.0, height=2.0, grou
     ground = marking.ground_lattice() if ground is None else ground
     mo = oracle.MarkingOracle(cfg, ground, static_map[:, :3])
     totals = dict(marked=0, cleared=0, clusters=0)
+    overlap = os.environ.get("DDDMR_MARKING_OVERLAP", "0") not in ("", "0")   # every update next to a pending tick
     with LocalPlanner([sc.theory], max_points=1 << 16) as lp:
         layer = marking.MarkingLayer(lp, cfg, ground, static_map[:, :3])
+        if overlap:
+            lp.setPlan(sc.plan)
         for k in range(n_updates):
             t_gb = poses(k)
             scan = scenes.lidar_scan(scene_of(k, cloud), sensor_xyz=(t_gb[0], t_gb[1], t_gb[2] + 0.5), seed=100 + k)
             lp.set_scan(scan, T_BS, t_gb, window, height)
             obs = lp.get_cloud()
-            st = layer.update(T_BS, t_gb)
+            if overlap:
+                lp.tick_begin(sc.theory.name.decode(), scenes.tick_input(pose=t_gb))
+                st = layer.update(T_BS, t_gb)
+                assert lp.tick_end().planner_state in (K.TRAJECTORY_FOUND, K.ALL_TRAJECTORIES_FAIL)
+            else:
+                st = layer.update(T_BS, t_gb)
             so = mo.update(obs[:, :3], T_BS, t_gb)
             got = (st.n_observation, st.n_clusters, st.n_marked, st.n_in_window, st.n_cleared, st.n_alive)
             want = (so.n_observation, so.n_clusters, so.n_marked, so.n_in_window, so.n_cleared, so.n_alive)
