@@ -54,6 +54,10 @@ def test_random_clouds_and_plans():
             pc[:nb, 3] = -1.0
             pc[nb:, 3] = 1.0
             r = float(rng.choice([0.02, 0.1, 0.25, 0.6]))
+            if os.environ.get("DDDMR_RANDOM_SHIFT"):         # cloud and plan kilometres from the map origin
+                off = np.array([float(v) for v in os.environ["DDDMR_RANDOM_SHIFT"].split(",")])
+                cloud[:, :3] = (cloud[:, :3].astype(np.float64) + off).astype(np.float32)
+                pc[:, :3] = (pc[:, :3].astype(np.float64) + off).astype(np.float32)
             lp.set_cloud(cloud)
             ratio, op, flags = lp.path_blocked(pc, r)
             o_ratio, o_op, o_flags = oracle.path_blocked(cloud, pc, r)
