@@ -169,6 +169,27 @@ public:
     }
   }
 
+  // the `global_marking` topic (pubUpdateLoop, :755-775): the reference publishes every alive marking's stored cluster
+  // (its 0.2 m-downsampled points); the device stores what the dGraph is computed from instead -- the same clusters
+  // projected on the robot's ground plane at 0.1 m -- so the published cloud is that: same footprints, z on the plane.
+  // Fetched on demand only (call it when the topic has subscribers).
+  template<class MarkingCloud>
+  int markingPointCloud(MarkingCloud & out) const
+  {
+    size_t n = 0;
+    int rc = dddmr_rollout_marking_get_points(ctx_, nullptr, nullptr, 0, &n);
+    if (rc != DDDMR_OK || n == 0) {return rc;}
+    std::vector<float> xyz(3 * n);
+    rc = dddmr_rollout_marking_get_points(ctx_, xyz.data(), nullptr, n, &n);
+    if (rc != DDDMR_OK) {return rc;}
+    for (size_t i = 0; i < n; ++i) {
+      typename MarkingCloud::PointType ipt;
+      ipt.x = xyz[3 * i]; ipt.y = xyz[3 * i + 1]; ipt.z = xyz[3 * i + 2];
+      out.push_back(ipt);
+    }
+    return DDDMR_OK;
+  }
+
 private:
   dddmr_rollout_ctx * ctx_ = nullptr;
   size_t n_ground_ = 0;

@@ -69,6 +69,8 @@ int dddmr_rollout_marking_update(dddmr_rollout_ctx*, const double*, const double
 int dddmr_rollout_marking_reset(dddmr_rollout_ctx*) { return DDDMR_OK; }
 int dddmr_rollout_marking_get_dgraph(dddmr_rollout_ctx*, double* v, size_t cap) { for (size_t i = 0; i < cap; ++i) v[i] = 0.5 * i; return DDDMR_OK; }
 int dddmr_rollout_marking_get_lethal(dddmr_rollout_ctx*, uint8_t* f, size_t cap) { for (size_t i = 0; i < cap; ++i) f[i] = i % 2; return DDDMR_OK; }
+int dddmr_rollout_marking_get_points(dddmr_rollout_ctx*, float* xyz, int32_t* vox, size_t cap, size_t* n) {
+  *n = 3; if (xyz) { assert(cap >= 3 && vox == nullptr); for (int i = 0; i < 9; ++i) xyz[i] = 0.25f * i; } return DDDMR_OK; }
 void dddmr_rollout_destroy(dddmr_rollout_ctx*) {}
 }
 
@@ -173,6 +175,9 @@ int main() {
   assert(ml.clearThenMark(b2s, g2b, &st) == DDDMR_OK && F.n_update == 1 && st.n_alive == 5 && ml.dGraphValue(4) == 2.0 && ml.dGraphValue(99) == 9999.0);
   ml.lethalPointCloud(ground, lethal);
   assert(lethal.points.size() == 3 && lethal.points[0].x == 1.f && lethal.points[2].x == 5.f);
+  Cloud<PointXYZI> gbl_marking;
+  assert(ml.markingPointCloud(gbl_marking) == DDDMR_OK && gbl_marking.points.size() == 3 && gbl_marking.points[1].x == 0.75f &&
+         gbl_marking.points[2].z == 2.0f);
   F.rc_mark = DDDMR_ERR_CAPACITY;
   assert(ml.clearThenMark(b2s, g2b) == DDDMR_ERR_CAPACITY);
 
