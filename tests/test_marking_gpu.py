@@ -464,3 +464,31 @@ def test_window_wider_than_the_band_table():
     scene_of = lambda k, c: c if k % 2 == 0 else c[np.hypot(c[:, 0] - 3.0, c[:, 1] - 1.0) > 1.5]
     totals, final = _run_sequence(cfg, walls, poses, scene_of, window=35.0, ground=ground, n_updates=5, fragile_tol=1e-5)
     assert totals["marked"] > 1000 and totals["cleared"] > 100
+
+
+def test_reset_in_the_middle_of_a_sequence():
+    """resetdGraph between updates (a new map / a relocalisation): store, dGraph and lethal set start over on both sides and
+    the updates that follow are identical again -- the fused route's between-update invariants (zeroed band and cell
+    counters, the published counters, the alive list) survive the reset."""
+    sc, cloud, walls, _ = _scene()
+    cfg = marking.shipped_config()
+    ground = marking.ground_lattice()
+    mo = oracle.MarkingOracle(cfg, ground, walls[:, :3])
+    with LocalPlanner([sc.theory], max_points=1 << 16) as lp:
+        layer = marking.MarkingLayer(lp, cfg, ground, walls[:, :3])
+        for k in range(9):
+            if k in (3, 6):
+                layer.reset(); mo.reset()
+                assert len(layer.voxels()) == 0
+            t_gb = (0.3 * k, 0.05 * k, 0.0, 0, 0, math.sin(0.04 * k), math.cos(0.04 * k))
+            scene_k = cloud if k % 2 else cloud[np.hypot(cloud[:, 0] - 2.5, cloud[:, 1]) > 1.0]
+            scan = scenes.lidar_scan(scene_k, sensor_xyz=(t_gb[0], t_gb[1], 0.5), seed=700 + k)
+            lp.set_scan(scan, T_BS, t_gb, 5.0, 2.0)
+            obs = lp.get_cloud()
+            st = layer.update(T_BS, t_gb)
+            so = mo.update(obs[:, :3], T_BS, t_gb)
+            assert (st.n_observation, st.n_clusters, st.n_marked, st.n_in_window, st.n_cleared, st.n_alive) == \
+                   (so.n_observation, so.n_clusters, so.n_marked, so.n_in_window, so.n_cleared, so.n_alive), f"update {k}"
+            assert _vset(layer.voxels()) == _vset(mo.voxels())
+            np.testing.assert_array_equal(layer.lethal(), mo.lethal())
+            np.testing.assert_array_equal(layer.dgraph(), mo.dgraph())
